@@ -1,0 +1,211 @@
+/*
+ * stacker.h — C ABI of the MI355X-native align-and-stack engine.
+ *
+ * This is the drop-in boundary for the hot path of eadf/libstacker.rs:
+ * everything a Rust `libstacker`-compatible shim needs to bind (see
+ * INTEGRATION.md for the `extern "C"` block a maintainer would add).
+ * Plain pointers and sizes only; no C++ / torch types cross this line.
+ *
+ * Conventions
+ *  - Images are interleaved, row-major, BGR channel order (OpenCV `Mat`
+ *    layout, which is what the reference hands around: utils.rs:128-144).
+ *  - `location` says whether a pointer is host (0) or device/HBM (1) memory.
+ *  - Every entry point returns an `stk_status`; the message of the last
+ *    failure is available from stk_last_error(). Nothing throws or aborts.
+ *  - A `stk_ctx` owns one GPU, one HIP stream and the HBM workspace; one call
+ *    at a time per context, any number of contexts per process.
+ *
+ * Reference citations are `file:line` under the reference checkout
+ * (`src/lib.rs`, `src/utils.rs`).
+ */
+#ifndef STACKER_H
+#define STACKER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: mirror StackerError (lib.rs:27-45) ------------------ */
+typedef enum {
+    STK_OK = 0,
+    STK_NOT_ENOUGH_FILES = 1, /* StackerError::NotEnoughFiles  lib.rs:31,155,725 */
+    STK_INVALID_PARAMS = 2,   /* StackerError::InvalidParams   lib.rs:41,324,377,876,883 */
+    STK_PROCESSING_ERROR = 3, /* StackerError::ProcessingError lib.rs:43,347,841 */
+    STK_BACKEND_ERROR = 4,    /* StackerError::OpenCvError     lib.rs:30 (ECC no-conv/NaN, bad types) */
+    STK_IO_ERROR = 5,         /* StackerError::IoError         lib.rs:36 */
+    STK_HIP_ERROR = 6,        /* no reference analogue: HIP runtime failure */
+    STK_NOT_IMPLEMENTED = 7   /* StackerError::NotImplemented  lib.rs:33 */
+} stk_status;
+
+/* ---- constants the reference passes through from OpenCV ---------------- */
+enum { STK_MOTION_TRANSLATION = 0, STK_MOTION_EUCLIDEAN = 1, /* MotionType lib.rs:603-609 */
+       STK_MOTION_AFFINE = 2, STK_MOTION_HOMOGRAPHY = 3 };
+enum { STK_METHOD_LEAST_SQUARES = 0, STK_METHOD_LMEDS = 4, /* KeyPointMatchParameters::method lib.rs:51 */
+       STK_METHOD_RANSAC = 8, STK_METHOD_RHO = 16 };
+enum { STK_BORDER_CONSTANT = 0, STK_BORDER_REPLICATE = 1, STK_BORDER_REFLECT = 2,
+       STK_BORDER_WRAP = 3, STK_BORDER_REFLECT_101 = 4, STK_BORDER_TRANSPARENT = 5 };
+enum { STK_HOST = 0, STK_DEVICE = 1 };
+enum { STK_DEPTH_U8 = 8, STK_DEPTH_U16 = 16, STK_DEPTH_F32 = 32 };
+
+/* ---- parameter mirrors -------------------------------------------------- */
+/* KeyPointMatchParameters, lib.rs:48-73; defaults utils.rs:250-261. */
+typedef struct {
+    int32_t method;                 /* STK_METHOD_* */
+    double  ransac_reproj_threshold;
+    float   match_keep_ratio;
+    float   match_ratio;
+    int32_t border_mode;            /* STK_BORDER_* */
+    double  border_value[4];        /* core::Scalar */
+} stk_keypoint_params;
+
+/* EccMatchParameters, lib.rs:611-623; Option<T> -> has_* flag + value
+ * (TermCriteria mapping utils.rs:159-170). */
+typedef struct {
+    int32_t motion_type;            /* STK_MOTION_* */
+    int32_t has_max_count;
+    int32_t max_count;
+    int32_t has_epsilon;
+    double  epsilon;
+    int32_t gauss_filt_size;
+} stk_ecc_params;
+
+/* A stack of decoded frames (what read_grey_and_f32's imread produced,
+ * utils.rs:132): data[0] is the reference frame. All frames share geometry. */
+typedef struct {
+    const void* const* data;        /* n pointers */
+    int32_t n;
+    int32_t width, height;
+    int32_t channels;               /* 3 (BGR); 1 is accepted by stage-level calls only */
+    int32_t depth;                  /* STK_DEPTH_* */
+    int32_t location;               /* STK_HOST | STK_DEVICE */
+    size_t  row_stride_bytes;       /* 0 = tightly packed */
+} stk_frames;
+
+/* Caller-allocated f32 image (the returned CV_32FC3 Mat, lib.rs:98,656). */
+typedef struct {
+    float*  data;
+    int32_t width, height, channels;
+    int32_t location;               /* STK_HOST | STK_DEVICE */
+    size_t  row_stride_bytes;       /* 0 = tightly packed */
+} stk_image_f32;
+
+/* Optional per-frame report (additive; the reference discards these). */
+typedef struct {
+    int32_t status;                 /* 0 used, 1 dropped (keypoint path), 2 error */
+    int32_t iterations;             /* ECC iterations executed */
+    double  rho;                    /* final ECC correlation coefficient */
+    int32_t n_keypoints;
+    int32_t n_matches;              /* after ratio test + truncation */
+    int32_t n_inliers;
+    int32_t reserved;
+    double  warp[9];                /* row-major 3x3 (2x3 padded with 0 0 1) */
+} stk_frame_stats;
+
+/* Device-side timing of the last whole-stack call, in milliseconds (HIP
+ * events on the context's stream) plus launch counts, for roofline reports. */
+typedef struct {
+    double prep_ms;        /* grey + blur + gradients (ECC) or ORB (keypoint) */
+    double align_ms;       /* ECC iterations or match+RANSAC */
+    double warp_ms;        /* warp + accumulate */
+    double finalize_ms;
+    int64_t ecc_iter_launches;      /* launches of the fused ECC iteration kernel */
+    int64_t ecc_slot_iterations;    /* sum over launches of active slots (frame-iterations) */
+    int64_t warp_launches;
+    int64_t warp_frames;
+} stk_timing;
+
+typedef struct stk_ctx stk_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+stk_status  stk_create(int32_t device_id, stk_ctx** out);
+void        stk_destroy(stk_ctx* ctx);
+const char* stk_last_error(const stk_ctx* ctx);    /* valid until the next call on ctx */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL
+ * restores the context's own stream. */
+stk_status  stk_set_stream(stk_ctx* ctx, void* hip_stream);
+stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
+/* Tuning knobs (do not change results): "ecc_slots" (frames iterated
+ * concurrently), "warp_subpixel_bits" (0 = exact f32 coordinates, OpenCV>=4.11
+ * kernels; 5 = classic 1/32-px quantised table), "profile" (per-stage events). */
+stk_status  stk_set_option(stk_ctx* ctx, const char* name, int64_t value);
+const char* stk_version(void);
+
+/* ---- whole-stack entry points: replace lib.rs:129-144 and lib.rs:702-717 -- */
+/* keypoint_match(files, params, scale_down_width) -> (dropped, Mat).
+ * scale_down_width <= 0 means None. */
+stk_status stk_keypoint_match(stk_ctx* ctx, const stk_frames* frames,
+                              const stk_keypoint_params* params, float scale_down_width,
+                              stk_image_f32* out, int32_t* dropped,
+                              stk_frame_stats* stats_or_null);
+/* ecc_match(files, params, scale_down_width) -> Mat. */
+stk_status stk_ecc_match(stk_ctx* ctx, const stk_frames* frames,
+                         const stk_ecc_params* params, float scale_down_width,
+                         stk_image_f32* out, stk_frame_stats* stats_or_null);
+
+/* ---- shard-level entry points (one process per GPU; frames[0] is always the
+ * reference frame, the remaining entries are this rank's slice of 1..N-1).
+ * They produce the UN-normalised f32 sum (the Rayon fold accumulator,
+ * lib.rs:306-316 / 807-814) in `sum` (device memory) and the number of frames
+ * added; the caller reduces sums/counts across ranks (RCCL) and then calls
+ * stk_finalize_mean once on the root. add_reference != 0 adds frame 0 itself
+ * (lib.rs:194-196, 752-754) — exactly one rank does that. */
+stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames,
+                               const stk_ecc_params* params, float scale_down_width,
+                               int32_t add_reference, stk_image_f32* sum,
+                               int32_t* n_added, stk_frame_stats* stats_or_null);
+stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames,
+                                    const stk_keypoint_params* params, float scale_down_width,
+                                    int32_t add_reference, stk_image_f32* sum,
+                                    int32_t* n_added, int32_t* n_dropped,
+                                    stk_frame_stats* stats_or_null);
+/* img / (n as f64)  ==  img * (float)(1.0/n)  (lib.rs:339-345, 836-839). In place if out==sum. */
+stk_status stk_finalize_mean(stk_ctx* ctx, const stk_image_f32* sum, int64_t n_frames,
+                             stk_image_f32* out);
+
+/* ---- stage-level entry points (parity tests bind these) ------------------ */
+/* cvt_color(BGR2GRAY) on the integer image, utils.rs:136-142. out: w*h of the input depth
+ * (u8 / u16 / f32), tightly packed, same location as the frame. */
+stk_status stk_grey(stk_ctx* ctx, const stk_frames* frame /* n==1 */, void* out);
+/* Mat::convert_to(CV_32F, alpha) utils.rs:133 (alpha = 1/255 there). */
+stk_status stk_convert_f32(stk_ctx* ctx, const stk_frames* frame /* n==1 */, double alpha,
+                           float* out);
+/* GaussianBlur(float(grey), g x g, sigma 0, REFLECT_101) as findTransformECC's setup does. */
+stk_status stk_gaussian_blur_f32(stk_ctx* ctx, const void* grey, int32_t depth, int32_t width,
+                                 int32_t height, int32_t location, int32_t ksize, float* out);
+/* video::find_transform_ecc(template, input, warp, motion, criteria, no mask, gauss) lib.rs:769-777.
+ * template/input: single-channel u8 (or f32) width x height, tightly packed.
+ * warp: 9 floats row-major in/out (2x3 motions use the first 6). rho/iterations optional. */
+stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* input,
+                                  int32_t depth, int32_t width, int32_t height, int32_t location,
+                                  const stk_ecc_params* params, float* warp, double* rho,
+                                  int32_t* iterations);
+/* imgproc::warp_perspective / warp_affine (INTER_LINEAR, no WARP_INVERSE_MAP: M is inverted)
+ * of convert(frame, 1/255)  fused with  acc += warped   (lib.rs:290-316, 780-814).
+ * M: 9 doubles row-major (affine: last row 0 0 1). acc: device or host f32 w*h*c.
+ * If accumulate == 0 the warped image overwrites acc. alpha is the convert scale. */
+stk_status stk_warp_accumulate(stk_ctx* ctx, const stk_frames* frame /* n==1 */, const double* M,
+                               int32_t is_affine, int32_t border_mode, const double* border_value,
+                               double alpha, int32_t accumulate, stk_image_f32* acc);
+
+/* ORB::create_def + detect_and_compute, utils.rs:174-183. keypoints: rows of 7 floats
+ * {x, y, size, angle, response, octave, class_id}; descriptors: rows of 32 bytes. */
+stk_status stk_orb_detect_and_compute(stk_ctx* ctx, const uint8_t* grey, int32_t width,
+                                      int32_t height, int32_t location, int32_t max_keypoints,
+                                      float* keypoints, uint8_t* descriptors, int32_t* n_keypoints);
+/* BFMatcher(NORM_HAMMING).knn_match(query, k=2) lib.rs:208-219. out rows {train0, dist0, train1, dist1}
+ * (-1 where the train set has fewer than 2 rows). Host pointers. */
+stk_status stk_bf_knn2_hamming(stk_ctx* ctx, const uint8_t* query, int32_t n_query,
+                               const uint8_t* train, int32_t n_train, int32_t* out);
+/* calib3d::find_homography(src_pts, dst_pts, mask, method, thr) lib.rs:267-276. Points are host
+ * float pairs. H: 9 doubles; *found = 0 when OpenCV would return an empty Mat. */
+stk_status stk_find_homography(stk_ctx* ctx, const float* src_pts, const float* dst_pts, int32_t n,
+                               int32_t method, double ransac_reproj_threshold, double* H,
+                               uint8_t* inlier_mask_or_null, int32_t* found);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STACKER_H */

@@ -1,0 +1,417 @@
+"""Host-side mirror of libstacker's public API over the C ABI (include/stacker.h).
+
+Same names, argument meaning and error behaviour as the reference (src/lib.rs):
+``keypoint_match(files, KeyPointMatchParameters, scale_down_width) -> (dropped, image)``
+(lib.rs:129-144) and ``ecc_match(files, EccMatchParameters, scale_down_width) -> image``
+(lib.rs:702-717); `StackerError` variants follow lib.rs:27-45. "files" are decoded frames here
+(numpy arrays on the host or torch tensors already resident in HBM, BGR interleaved like
+imread(IMREAD_UNCHANGED) returns, utils.rs:132); the first one is the reference frame.
+
+All arithmetic happens in libstacker_amd.so (hand-written HIP for gfx950). This module only
+marshals pointers; it has no CPU fallback and raises if the library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+
+# OpenCV constants the reference passes through
+RANSAC, LMEDS, RHO, LEAST_SQUARES = 8, 4, 16, 0
+BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101, BORDER_TRANSPARENT = range(6)
+HOST, DEVICE = 0, 1
+
+
+class StackerError(Exception):
+    """Base of the reference's StackerError enum (lib.rs:27-45)."""
+
+
+class NotEnoughFiles(StackerError):
+    pass
+
+
+class InvalidParams(StackerError):
+    pass
+
+
+class ProcessingError(StackerError):
+    pass
+
+
+class OpenCvError(StackerError):
+    """The reference's OpenCvError: failures the OpenCV backend would have raised (ECC no-convergence ...)."""
+
+
+class IoError(StackerError):
+    pass
+
+
+class HipError(StackerError):
+    pass
+
+
+class NotImplementedYet(StackerError):
+    pass
+
+
+_STATUS_EXC = {1: NotEnoughFiles, 2: InvalidParams, 3: ProcessingError, 4: OpenCvError, 5: IoError, 6: HipError,
+               7: NotImplementedYet}
+
+
+class MotionType(enum.IntEnum):   # lib.rs:603-609 (= OpenCV MOTION_*)
+    Translation = 0
+    Euclidean = 1
+    Affine = 2
+    Homography = 3
+
+
+@dataclass
+class KeyPointMatchParameters:    # lib.rs:48-73, defaults utils.rs:250-261
+    method: int = RANSAC
+    ransac_reproj_threshold: float = 3.0
+    match_keep_ratio: float = 0.75
+    match_ratio: float = 0.8
+    border_mode: int = BORDER_CONSTANT
+    border_value: Sequence[float] = field(default_factory=lambda: (0.0, 0.0, 0.0, 0.0))
+
+    def _c(self) -> _ffi.KeypointParams:
+        bv = (list(self.border_value) + [0.0] * 4)[:4]
+        return _ffi.KeypointParams(int(self.method), float(self.ransac_reproj_threshold), float(self.match_keep_ratio),
+                                   float(self.match_ratio), int(self.border_mode), (C.c_double * 4)(*bv))
+
+
+@dataclass
+class EccMatchParameters:         # lib.rs:611-623 (no Default in the reference)
+    motion_type: MotionType
+    max_count: Optional[int]
+    epsilon: Optional[float]
+    gauss_filt_size: int
+
+    def _c(self) -> _ffi.EccParams:
+        return _ffi.EccParams(int(self.motion_type), int(self.max_count is not None), int(self.max_count or 0),
+                              int(self.epsilon is not None), float(self.epsilon or 0.0), int(self.gauss_filt_size))
+
+    def term_criteria(self):
+        """TermCriteria{typ, max_count, epsilon} as utils.rs:159-170 builds it (COUNT=1, EPS=2)."""
+        typ = (1 if self.max_count is not None else 0) | (2 if self.epsilon is not None else 0)
+        return typ, (self.max_count or 0), (self.epsilon or 0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+_DEPTH = {"uint8": 8, "uint16": 16, "float32": 32}
+
+
+class _Marshalled:
+    """Pointers + geometry of a frame stack, keeping the owners alive."""
+
+    def __init__(self, frames):
+        if _is_torch(frames) and frames.dim() == 4:
+            frames = list(frames.unbind(0))
+        elif isinstance(frames, np.ndarray) and frames.ndim == 4:
+            frames = list(frames)
+        frames = list(frames)
+        self.keep = []
+        self.n = len(frames)
+        self.location = HOST
+        self.torch_device = None
+        ptrs = []
+        geo = None
+        for f in frames:
+            if _is_torch(f):
+                if f.is_cuda:
+                    self.location = DEVICE
+                    self.torch_device = f.device
+                    t = f.contiguous()
+                    self.keep.append(t)
+                    ptrs.append(t.data_ptr())
+                    g = (tuple(t.shape), str(t.dtype).replace("torch.", ""))
+                else:
+                    a = np.ascontiguousarray(f.numpy())
+                    self.keep.append(a)
+                    ptrs.append(a.ctypes.data)
+                    g = (a.shape, str(a.dtype))
+            else:
+                a = np.ascontiguousarray(f)
+                self.keep.append(a)
+                ptrs.append(a.ctypes.data)
+                g = (a.shape, str(a.dtype))
+            if len(g[0]) == 2:
+                g = ((g[0][0], g[0][1], 1), g[1])
+            if geo is None:
+                geo = g
+            elif g != geo:
+                raise InvalidParams("all frames must share size, channels and dtype")
+        if self.n:
+            (self.h, self.w, self.c), dt = geo
+            if dt not in _DEPTH:
+                raise InvalidParams(f"unsupported pixel type {dt}")
+            self.depth = _DEPTH[dt]
+        else:
+            self.h = self.w = self.c = 0
+            self.depth = 8
+        self.ptr_arr = (C.c_void_p * max(self.n, 1))(*ptrs)
+        self.c_frames = _ffi.Frames(C.cast(self.ptr_arr, C.POINTER(C.c_void_p)), self.n, self.w, self.h, self.c,
+                                    self.depth, self.location, 0)
+
+
+class Stacker:
+    """One GPU context (stk_ctx). Not thread-safe: one call at a time per instance."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _ffi.load()
+        h = C.c_void_p()
+        st = self._lib.stk_create(int(device), C.byref(h))
+        if st != 0:
+            raise HipError(f"stk_create(device={device}) failed with status {st} (no usable GPU?)")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.stk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _check(self, st: int):
+        if st != 0:
+            msg = self._lib.stk_last_error(self._h)
+            raise _STATUS_EXC.get(st, StackerError)((msg or b"").decode("utf-8", "replace"))
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.stk_set_option(self._h, name.encode(), int(value)))
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self._lib.stk_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def timing(self) -> dict:
+        t = _ffi.Timing()
+        self._check(self._lib.stk_get_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _ffi.Timing._fields_}
+
+    def _out_image(self, m: _Marshalled):
+        """f32 HxWxC output placed where the inputs live."""
+        if m.location == DEVICE:
+            import torch
+            out = torch.empty((m.h, m.w, m.c), dtype=torch.float32, device=m.torch_device)
+            img = _ffi.ImageF32(out.data_ptr(), m.w, m.h, m.c, DEVICE, 0)
+        else:
+            out = np.empty((m.h, m.w, m.c), np.float32)
+            img = _ffi.ImageF32(out.ctypes.data, m.w, m.h, m.c, HOST, 0)
+        return out, img
+
+    @staticmethod
+    def _stats_list(stats, n):
+        return [dict(status=s.status, iterations=s.iterations, rho=s.rho, n_keypoints=s.n_keypoints,
+                     n_matches=s.n_matches, n_inliers=s.n_inliers, warp=np.array(list(s.warp)).reshape(3, 3))
+                for s in stats[:n]]
+
+    # -- whole-stack API (the reference's two entry points) ---------------------------------------
+    def ecc_match(self, files, params: EccMatchParameters, scale_down_width: Optional[float] = None,
+                  return_stats: bool = False):
+        m = _Marshalled(files)
+        if m.n == 0:
+            raise NotEnoughFiles("Not enough files")
+        out, img = self._out_image(m)
+        stats = (_ffi.FrameStats * m.n)()
+        p = params._c()
+        st = self._lib.stk_ecc_match(self._h, C.byref(m.c_frames), C.byref(p), float(scale_down_width or 0.0),
+                                     C.byref(img), stats)
+        self._check(st)
+        return (out, self._stats_list(stats, m.n)) if return_stats else out
+
+    def keypoint_match(self, files, params: KeyPointMatchParameters, scale_down_width: Optional[float] = None,
+                       return_stats: bool = False):
+        m = _Marshalled(files)
+        if m.n == 0:
+            raise NotEnoughFiles("Not enough files")
+        out, img = self._out_image(m)
+        stats = (_ffi.FrameStats * m.n)()
+        dropped = C.c_int32(0)
+        p = params._c()
+        st = self._lib.stk_keypoint_match(self._h, C.byref(m.c_frames), C.byref(p), float(scale_down_width or 0.0),
+                                          C.byref(img), C.byref(dropped), stats)
+        self._check(st)
+        return (dropped.value, out, self._stats_list(stats, m.n)) if return_stats else (dropped.value, out)
+
+    # -- shard-level (one process per GPU; frames[0] = reference frame) ------------------------------
+    def ecc_match_shard(self, files, params: EccMatchParameters, add_reference: bool, sum_out,
+                        scale_down_width: Optional[float] = None):
+        """Un-normalised f32 sum of this rank's aligned frames into `sum_out` (cuda tensor HxWx3)."""
+        m = _Marshalled(files)
+        if m.n == 0:
+            raise NotEnoughFiles("Not enough files")
+        img = _ffi.ImageF32(sum_out.data_ptr(), m.w, m.h, 3, DEVICE, 0)
+        added = C.c_int32(0)
+        stats = (_ffi.FrameStats * m.n)()
+        p = params._c()
+        st = self._lib.stk_ecc_match_shard(self._h, C.byref(m.c_frames), C.byref(p), float(scale_down_width or 0.0),
+                                           int(bool(add_reference)), C.byref(img), C.byref(added), stats)
+        self._check(st)
+        return added.value, self._stats_list(stats, m.n)
+
+    def keypoint_match_shard(self, files, params: KeyPointMatchParameters, add_reference: bool, sum_out,
+                             scale_down_width: Optional[float] = None):
+        m = _Marshalled(files)
+        if m.n == 0:
+            raise NotEnoughFiles("Not enough files")
+        img = _ffi.ImageF32(sum_out.data_ptr(), m.w, m.h, 3, DEVICE, 0)
+        added, dropped = C.c_int32(0), C.c_int32(0)
+        stats = (_ffi.FrameStats * m.n)()
+        p = params._c()
+        st = self._lib.stk_keypoint_match_shard(self._h, C.byref(m.c_frames), C.byref(p),
+                                                float(scale_down_width or 0.0), int(bool(add_reference)),
+                                                C.byref(img), C.byref(added), C.byref(dropped), stats)
+        self._check(st)
+        return added.value, dropped.value, self._stats_list(stats, m.n)
+
+    def finalize_mean(self, sum_img, n_frames: int, out=None):
+        """img / n  (lib.rs:339-345, 836-839) on a cuda tensor; in place when out is None."""
+        h, w, c = sum_img.shape
+        out = sum_img if out is None else out
+        a = _ffi.ImageF32(sum_img.data_ptr(), w, h, c, DEVICE, 0)
+        b = _ffi.ImageF32(out.data_ptr(), w, h, c, DEVICE, 0)
+        self._check(self._lib.stk_finalize_mean(self._h, C.byref(a), int(n_frames), C.byref(b)))
+        return out
+
+    # -- stage-level (parity tests) ------------------------------------------------------------------
+    def grey(self, frame):
+        m = _Marshalled([frame])
+        if m.location == DEVICE:
+            import torch
+            out = torch.empty((m.h, m.w), dtype=m.keep[0].dtype, device=m.torch_device)
+            ptr = out.data_ptr()
+        else:
+            out = np.empty((m.h, m.w), m.keep[0].dtype)
+            ptr = out.ctypes.data
+        self._check(self._lib.stk_grey(self._h, C.byref(m.c_frames), C.c_void_p(ptr)))
+        return out
+
+    def convert_f32(self, frame, alpha: float = 1.0 / 255.0):
+        m = _Marshalled([frame])
+        if m.location == DEVICE:
+            import torch
+            out = torch.empty(tuple(m.keep[0].shape), dtype=torch.float32, device=m.torch_device)
+            ptr = out.data_ptr()
+        else:
+            out = np.empty(m.keep[0].shape, np.float32)
+            ptr = out.ctypes.data
+        self._check(self._lib.stk_convert_f32(self._h, C.byref(m.c_frames), float(alpha), C.c_void_p(ptr)))
+        return out
+
+    def gaussian_blur_f32(self, grey, ksize: int):
+        g = np.ascontiguousarray(grey)
+        h, w = g.shape
+        out = np.empty((h, w), np.float32)
+        self._check(self._lib.stk_gaussian_blur_f32(self._h, C.c_void_p(g.ctypes.data), _DEPTH[str(g.dtype)], w, h,
+                                                    HOST, int(ksize), C.c_void_p(out.ctypes.data)))
+        return out
+
+    def find_transform_ecc(self, templ, inp, warp, params: EccMatchParameters):
+        """video::find_transform_ecc(template, input, warp, ...) lib.rs:769-777 -> (warp3x3 f32, rho, iterations)."""
+        t = np.ascontiguousarray(templ)
+        i = np.ascontiguousarray(inp)
+        if t.shape != i.shape or t.dtype != i.dtype:
+            raise InvalidParams("template and input must share size and type")
+        wm = np.eye(3, dtype=np.float32)
+        wv = np.asarray(warp, np.float32)
+        wm[: wv.shape[0], :] = wv
+        rho, its = C.c_double(0), C.c_int32(0)
+        p = params._c()
+        st = self._lib.stk_find_transform_ecc(self._h, C.c_void_p(t.ctypes.data), C.c_void_p(i.ctypes.data),
+                                              _DEPTH[str(t.dtype)], t.shape[1], t.shape[0], HOST, C.byref(p),
+                                              C.c_void_p(wm.ctypes.data), C.byref(rho), C.byref(its))
+        self._check(st)
+        return wm, rho.value, its.value
+
+    def warp_accumulate(self, frame, M, *, is_affine=False, border_mode=BORDER_CONSTANT, border_value=(0, 0, 0, 0),
+                        alpha=1.0 / 255.0, acc=None):
+        """warp_perspective/warp_affine(convert(frame, alpha), M) (+ acc). Returns the f32 image."""
+        m = _Marshalled([frame])
+        Md = np.ascontiguousarray(np.asarray(M, np.float64).reshape(-1))
+        if Md.size == 6:
+            Md = np.concatenate([Md, [0.0, 0.0, 1.0]])
+        bv = np.asarray((list(border_value) + [0.0] * 4)[:4], np.float64)
+        accumulate = acc is not None
+        if accumulate:
+            out = acc
+            if _is_torch(out):
+                img = _ffi.ImageF32(out.data_ptr(), m.w, m.h, m.c, DEVICE if out.is_cuda else HOST, 0)
+            else:
+                img = _ffi.ImageF32(out.ctypes.data, m.w, m.h, m.c, HOST, 0)
+        else:
+            out, img = self._out_image(m)
+        st = self._lib.stk_warp_accumulate(self._h, C.byref(m.c_frames), C.c_void_p(Md.ctypes.data), int(is_affine),
+                                           int(border_mode), C.c_void_p(bv.ctypes.data), float(alpha),
+                                           int(accumulate), C.byref(img))
+        self._check(st)
+        return out
+
+    def orb_detect_and_compute(self, grey, max_keypoints: int = 2000):
+        g = np.ascontiguousarray(grey, np.uint8)
+        h, w = g.shape
+        kps = np.zeros((max_keypoints, 7), np.float32)
+        des = np.zeros((max_keypoints, 32), np.uint8)
+        n = C.c_int32(0)
+        st = self._lib.stk_orb_detect_and_compute(self._h, C.c_void_p(g.ctypes.data), w, h, HOST, int(max_keypoints),
+                                                  C.c_void_p(kps.ctypes.data), C.c_void_p(des.ctypes.data), C.byref(n))
+        self._check(st)
+        return kps[: n.value].copy(), des[: n.value].copy()
+
+    def bf_knn2_hamming(self, query, train):
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        out = np.full((q.shape[0], 4), -1, np.int32)
+        st = self._lib.stk_bf_knn2_hamming(self._h, C.c_void_p(q.ctypes.data), q.shape[0], C.c_void_p(t.ctypes.data),
+                                           t.shape[0], C.c_void_p(out.ctypes.data))
+        self._check(st)
+        return out
+
+    def find_homography(self, src_pts, dst_pts, method: int = RANSAC, ransac_reproj_threshold: float = 3.0):
+        s = np.ascontiguousarray(src_pts, np.float32).reshape(-1, 2)
+        d = np.ascontiguousarray(dst_pts, np.float32).reshape(-1, 2)
+        H = np.zeros(9, np.float64)
+        mask = np.zeros(s.shape[0], np.uint8)
+        found = C.c_int32(0)
+        st = self._lib.stk_find_homography(self._h, C.c_void_p(s.ctypes.data), C.c_void_p(d.ctypes.data), s.shape[0],
+                                           int(method), float(ransac_reproj_threshold), C.c_void_p(H.ctypes.data),
+                                           C.c_void_p(mask.ctypes.data), C.byref(found))
+        self._check(st)
+        return (H.reshape(3, 3) if found.value else None), mask
+
+
+_default: dict[int, Stacker] = {}
+
+
+def default_stacker(device: int = 0) -> Stacker:
+    if device not in _default:
+        _default[device] = Stacker(device)
+    return _default[device]
+
+
+def keypoint_match(files, params: KeyPointMatchParameters, scale_down_width: Optional[float] = None):
+    """Drop-in for libstacker::keypoint_match (lib.rs:129-144): returns (dropped, image)."""
+    return default_stacker().keypoint_match(files, params, scale_down_width)
+
+
+def ecc_match(files, params: EccMatchParameters, scale_down_width: Optional[float] = None):
+    """Drop-in for libstacker::ecc_match (lib.rs:702-717): returns the stacked f32 image."""
+    return default_stacker().ecc_match(files, params, scale_down_width)

@@ -1,0 +1,122 @@
+// common.h — shared declarations of the HIP engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/stacker.h"
+
+namespace stk {
+
+// ---------------------------------------------------------------------------------------------
+// Device data layout (all in HBM, owned by the context's workspace)
+//
+//  * frames          interleaved BGR u8/u16/f32 as handed in (OpenCV Mat layout).
+//  * reference planes (ECC "input" = frame 0, shared by every frame of the stack):
+//        three f32 planes  I (blurred grey), gx, gy  each (H+4) x ref_stride with a 2-pixel ZERO
+//        border on every side, so a bilinear footprint with BORDER_CONSTANT 0 is four
+//        unconditional loads after clamping the integer coordinate to [-2, W] x [-2, H].
+//  * templates       one blurred-grey f32 plane per moving frame, row stride rounded up to a
+//        multiple of 4 floats so each lane streams aligned 16-byte quads.
+//  * accumulator     f32 W*H*3 running sum (the Rayon fold accumulator, lib.rs:306-316, 807-814).
+// ---------------------------------------------------------------------------------------------
+
+constexpr int REF_PAD = 2;
+
+struct RefPlanes {
+    const float* I;   // pointer to pixel (0,0) inside the padded plane
+    const float* gx;
+    const float* gy;
+    int stride;       // floats per padded row
+    int w, h;
+};
+
+// One ECC "slot": a frame currently being iterated. Lives in device memory and is advanced
+// entirely on the device (solve kernel); the host only polls EccQueue::frames_done.
+struct EccSlot {
+    int   frame;        // index into the template array, -1 = idle
+    int   iter;         // iterations executed so far
+    float warp[9];      // current map, row-major 3x3
+    float cI, cT;       // centring offsets (previous iteration's f32 means) for the moment sums
+    double rho, last_rho;
+};
+
+struct EccFrameResult {
+    float  warp[9];
+    int    iters;
+    int    status;      // 0 ok, 1 NaN, 2 lambda_d <= 0, 3 not run
+    double rho;
+};
+
+struct EccQueue {
+    int next_frame;     // next template index to hand to a free slot
+    int n_frames;       // number of templates
+    int frames_done;
+    int pad;
+};
+
+struct EccCriteria {
+    int    n_iter;      // COUNT ? max_count : 200
+    double eps;         // EPS ? epsilon : -1
+};
+
+// number of moment sums produced per slot and iteration for P warp parameters
+__host__ __device__ constexpr int ecc_nsums(int P) { return P * (P + 1) / 2 + 3 * P + 6; }
+constexpr int ECC_MAX_SUMS = ecc_nsums(8);   // 66
+
+struct EccIterArgs {
+    RefPlanes ref;
+    const float* templates;      // n_frames planes
+    size_t templ_plane_stride;   // floats between consecutive templates
+    int templ_row_stride;        // floats per template row (multiple of 4)
+    int tw, th;
+    EccSlot* slots;
+    int n_slots;
+    int nb;                      // blocks per slot (multiple of 8)
+    double* partials;            // [n_slots][nb][nsums]
+};
+
+struct WarpFrame {
+    const void* src;
+    float  M[9];                 // destination -> source map, f32 (subpixel_bits == 0)
+    double Md[9];                // same in double (classic quantised path)
+};
+
+struct WarpArgs {
+    const WarpFrame* frames;
+    int n_frames;
+    int sw, sh, cn;
+    size_t src_stride;           // elements per source row
+    float alpha;
+    int border_mode;
+    float bv[4];
+    float* acc;
+    int dw, dh;
+    size_t acc_stride;           // floats per accumulator row
+    int accumulate;              // 0: overwrite, 1: acc += sum of warped frames
+    int is_affine;
+    int subpixel_bits;           // 0 or 5
+};
+
+// ---- kernel launchers (defined in the .hip files) -------------------------------------------
+hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void* out, hipStream_t s);
+hipError_t launch_convert_f32(const void* src, int depth, size_t n, float alpha, float* out, hipStream_t s);
+// BGR (cn==3) or grey (cn==1) image -> GaussianBlur(float(grey), ksize) f32 plane with row stride out_stride
+hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, size_t stride_bytes, int ksize,
+                            float* out, int out_stride, hipStream_t s);
+// blurred plane (stride in_stride) -> padded I/gx/gy planes
+hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy,
+                             int ref_stride, hipStream_t s);
+hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, hipStream_t s);
+hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
+                            EccFrameResult* results, hipStream_t s);
+hipError_t launch_ecc_init(EccSlot* slots, int n_slots, EccQueue* queue, int n_frames, EccFrameResult* results,
+                           const float* init_warps /* n_frames*9 or null */, hipStream_t s);
+hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s);
+hipError_t launch_scale(const float* in, float* out, size_t n, float scale, hipStream_t s);
+hipError_t launch_add(float* acc, const float* in, size_t n, hipStream_t s);
+
+}  // namespace stk

@@ -1,0 +1,203 @@
+// kernels_prep.hip — per-frame preparation kernels (gfx950):
+//   grey           cvt_color(BGR2GRAY) on the integer image            (utils.rs:136-142)
+//   convert_f32    Mat::convert_to(CV_32F, alpha)                      (utils.rs:133,     SURVEY A2)
+//   grey_blur      BGR -> grey -> GaussianBlur(float(grey), g x g, sigma 0, REFLECT_101) in ONE pass:
+//                  the grey tile with its halo is staged in LDS, row-filtered into a second LDS
+//                  tile and column-filtered to HBM (findTransformECC setup step 3, SURVEY §8a-E*)
+//   ref_planes     blurred frame 0 -> zero-padded I / gx / gy planes    (ECC setup step 5)
+// HBM-bound: grey_blur reads 3 B/px (u8 BGR) and writes 4 B/px.
+#include "common.h"
+
+namespace stk {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// ---- grey -------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t grey_u8(unsigned b, unsigned g, unsigned r) {
+    return (uint8_t)((b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15);
+}
+__device__ __forceinline__ uint16_t grey_u16(unsigned b, unsigned g, unsigned r) {
+    return (uint16_t)((b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14);
+}
+__device__ __forceinline__ float grey_f32(float b, float g, float r) {
+    return b * 0.114f + g * 0.587f + r * 0.299f;   // -ffp-contract=off: three roundings, as the oracle
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grey_kernel(const T* __restrict__ src, size_t stride, int w, int h,
+                                                   T* __restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const T* p = src + (size_t)y * stride + (size_t)x * 3;
+    T v;
+    if constexpr (sizeof(T) == 1) v = grey_u8(p[0], p[1], p[2]);
+    else if constexpr (sizeof(T) == 2) v = grey_u16(p[0], p[1], p[2]);
+    else v = grey_f32(p[0], p[1], p[2]);
+    out[(size_t)y * w + x] = v;
+}
+
+hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void* out, hipStream_t s) {
+    dim3 grid((w + 255) / 256, h);
+    if (depth == 8) grey_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)bgr, stride_bytes, w, h, (uint8_t*)out);
+    else if (depth == 16) grey_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)bgr, stride_bytes / 2, w, h, (uint16_t*)out);
+    else grey_kernel<float><<<grid, 256, 0, s>>>((const float*)bgr, stride_bytes / 4, w, h, (float*)out);
+    return hipGetLastError();
+}
+
+// ---- convert ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void convert_kernel(const T* __restrict__ src, size_t n, float alpha,
+                                                      float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i < n; i += step) out[i] = (float)src[i] * alpha;
+}
+
+hipError_t launch_convert_f32(const void* src, int depth, size_t n, float alpha, float* out, hipStream_t s) {
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    if (blocks < 1) blocks = 1;
+    if (depth == 8) convert_kernel<uint8_t><<<blocks, 256, 0, s>>>((const uint8_t*)src, n, alpha, out);
+    else if (depth == 16) convert_kernel<uint16_t><<<blocks, 256, 0, s>>>((const uint16_t*)src, n, alpha, out);
+    else convert_kernel<float><<<blocks, 256, 0, s>>>((const float*)src, n, alpha, out);
+    return hipGetLastError();
+}
+
+// ---- fused grey + Gaussian blur ---------------------------------------------------------------
+struct GaussTaps { float k[16]; int r; };   // k[i] = weight at distance i from the centre
+
+static bool gaussian_taps(int ksize, GaussTaps& t) {
+    if (ksize <= 0 || ksize % 2 == 0 || ksize > 31) return false;
+    t.r = ksize / 2;
+    static const float tab[4][4] = {{1.f, 0, 0, 0}, {0.5f, 0.25f, 0, 0}, {0.375f, 0.25f, 0.0625f, 0},
+                                    {0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    for (int i = 0; i < 16; i++) t.k[i] = 0;
+    if (ksize <= 7) { for (int i = 0; i <= t.r; i++) t.k[i] = tab[t.r][i]; return true; }
+    // cv::getGaussianKernel(n, sigma<=0): sigma = 0.3*((n-1)*0.5-1)+0.8, normalised exp(-x^2/2s^2), double -> f32
+    const double sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8, sc = -0.5 / (sigma * sigma);
+    double sum = 0, v[32];
+    for (int i = 0; i < ksize; i++) { double x = i - (ksize - 1) * 0.5; v[i] = std::exp(sc * x * x); sum += v[i]; }
+    for (int i = 0; i <= t.r; i++) t.k[i] = (float)(v[t.r + i] * (1.0 / sum));
+    return true;
+}
+
+constexpr int BT_X = 64, BT_Y = 16;
+
+template <typename T, int CN>
+__global__ __launch_bounds__(256) void grey_blur_kernel(const T* __restrict__ src, size_t stride, int w, int h,
+                                                        GaussTaps taps, float* __restrict__ out, int out_stride) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int r = taps.r;
+    const int GW = BT_X + 2 * r, GH = BT_Y + 2 * r;
+    float* G = lds;                 // [GH][GW]  grey tile with halo
+    float* R = lds + GH * GW;       // [GH][BT_X] row-filtered
+    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < GH * GW; i += 256) {
+        const int ty = i / GW, tx = i - ty * GW;
+        const int sx = reflect101(x0 - r + tx, w), sy = reflect101(y0 - r + ty, h);
+        const T* p = src + (size_t)sy * stride + (size_t)sx * CN;
+        float v;
+        if constexpr (CN == 1) v = (float)p[0];
+        else if constexpr (sizeof(T) == 1) v = (float)grey_u8(p[0], p[1], p[2]);
+        else v = grey_f32((float)p[0], (float)p[1], (float)p[2]);
+        G[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < GH * BT_X; i += 256) {
+        const int ty = i / BT_X, tx = i - ty * BT_X;
+        const float* g = G + ty * GW + tx + r;
+        float s = taps.k[0] * g[0];
+        for (int j = 1; j <= r; j++) s += taps.k[j] * (g[-j] + g[j]);
+        R[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < BT_Y * BT_X; i += 256) {
+        const int ty = i / BT_X, tx = i - ty * BT_X;
+        const int x = x0 + tx, y = y0 + ty;
+        const float* c = R + (ty + r) * BT_X + tx;
+        float s = taps.k[0] * c[0];
+        for (int j = 1; j <= r; j++) s += taps.k[j] * (c[-j * BT_X] + c[j * BT_X]);
+        if (x < w && y < h) out[(size_t)y * out_stride + x] = s;
+    }
+}
+
+hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, size_t stride_bytes, int ksize,
+                            float* out, int out_stride, hipStream_t s) {
+    GaussTaps taps;
+    if (!gaussian_taps(ksize, taps)) return hipErrorInvalidValue;
+    const int r = taps.r;
+    const size_t lds_bytes = (size_t)((BT_Y + 2 * r) * (BT_X + 2 * r) + (BT_Y + 2 * r) * BT_X) * sizeof(float);
+    dim3 grid((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y);
+    if (depth == 8 && cn == 3) grey_blur_kernel<uint8_t, 3><<<grid, 256, lds_bytes, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+    else if (depth == 8 && cn == 1) grey_blur_kernel<uint8_t, 1><<<grid, 256, lds_bytes, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+    else if (depth == 32 && cn == 3) grey_blur_kernel<float, 3><<<grid, 256, lds_bytes, s>>>((const float*)src, stride_bytes / 4, w, h, taps, out, out_stride);
+    else if (depth == 32 && cn == 1) grey_blur_kernel<float, 1><<<grid, 256, lds_bytes, s>>>((const float*)src, stride_bytes / 4, w, h, taps, out, out_stride);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- reference planes -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ref_planes_kernel(const float* __restrict__ b, int in_stride, int w, int h,
+                                                         float* __restrict__ I, float* __restrict__ gx,
+                                                         float* __restrict__ gy, int rs) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float* row = b + (size_t)y * in_stride;
+    const float* up = b + (size_t)reflect101(y - 1, h) * in_stride;
+    const float* dn = b + (size_t)reflect101(y + 1, h) * in_stride;
+    const size_t o = (size_t)y * rs + x;
+    I[o] = row[x];
+    gx[o] = -0.5f * row[reflect101(x - 1, w)] + 0.5f * row[reflect101(x + 1, w)];
+    gy[o] = -0.5f * up[x] + 0.5f * dn[x];
+}
+
+hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy,
+                             int ref_stride, hipStream_t s) {
+    dim3 grid((w + 255) / 256, h);
+    ref_planes_kernel<<<grid, 256, 0, s>>>(blurred, in_stride, w, h, I, gx, gy, ref_stride);
+    return hipGetLastError();
+}
+
+// ---- elementwise helpers ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n,
+                                                    float sc) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t step = (size_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += step) {
+        float4 v = *reinterpret_cast<const float4*>(in + i);
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        *reinterpret_cast<float4*>(out + i) = v;
+    }
+    if (i < n && i + 3 >= n) for (size_t j = i; j < n; j++) out[j] = in[j] * sc;
+}
+
+hipError_t launch_scale(const float* in, float* out, size_t n, float sc, hipStream_t s) {
+    int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048);
+    scale_kernel<<<blocks, 256, 0, s>>>(in, out, n, sc);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ acc, const float* __restrict__ in, size_t n) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t step = (size_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += step) {
+        float4 a = *reinterpret_cast<float4*>(acc + i);
+        const float4 v = *reinterpret_cast<const float4*>(in + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        *reinterpret_cast<float4*>(acc + i) = a;
+    }
+    if (i < n && i + 3 >= n) for (size_t j = i; j < n; j++) acc[j] += in[j];
+}
+
+hipError_t launch_add(float* acc, const float* in, size_t n, hipStream_t s) {
+    int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048);
+    add_kernel<<<blocks, 256, 0, s>>>(acc, in, n);
+    return hipGetLastError();
+}
+
+}  // namespace stk

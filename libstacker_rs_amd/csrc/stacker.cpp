@@ -1,0 +1,601 @@
+// stacker.cpp — host runtime and C ABI (include/stacker.h) of the MI355X align-and-stack engine.
+//
+// Mirrors the reference's drivers: ecc_match_no_scaling (lib.rs:719-847) and
+// keypoint_match_no_scale (lib.rs:146-353). Where the reference runs a Rayon map-reduce over
+// frame indices with one f32 accumulator per worker thread, this runtime keeps every frame of the
+// shard resident in HBM, runs the alignment of ALL frames as a device-side work queue and then
+// folds every warped frame into one accumulator in a single launch.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+#include "keypoint.h"
+
+using namespace stk;
+
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + (bytes >> 3);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct stk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    int opt_ecc_slots = 0;        // 0 = auto
+    int opt_subpixel_bits = 0;
+    int opt_profile = 1;
+    int opt_ecc_chunk = 4;
+    stk_timing timing{};
+    hipEvent_t ev[8] = {};
+    hipEvent_t poll_ev[2] = {};
+    int* host_done = nullptr;     // pinned, 2 ints
+    // workspace
+    DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
+    KeypointWorkspace* kp = nullptr;
+};
+
+static stk_status fail(stk_ctx* ctx, stk_status st, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return st;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, STK_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+static size_t frame_row_bytes(const stk_frames* f) {
+    return f->row_stride_bytes ? f->row_stride_bytes : (size_t)f->width * f->channels * (f->depth / 8);
+}
+
+// 3x3 inverse by the adjugate in double (cv::invert on a 3x3 CV_64F) and invertAffineTransform.
+static void invert3x3(const double* m, double* o) {
+    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (d == 0.0) { for (int i = 0; i < 9; i++) o[i] = 0; return; }
+    d = 1.0 / d;
+    double t[9] = {(m[4] * m[8] - m[5] * m[7]) * d, (m[2] * m[7] - m[1] * m[8]) * d, (m[1] * m[5] - m[2] * m[4]) * d,
+                   (m[5] * m[6] - m[3] * m[8]) * d, (m[0] * m[8] - m[2] * m[6]) * d, (m[2] * m[3] - m[0] * m[5]) * d,
+                   (m[3] * m[7] - m[4] * m[6]) * d, (m[1] * m[6] - m[0] * m[7]) * d, (m[0] * m[4] - m[1] * m[3]) * d};
+    for (int i = 0; i < 9; i++) o[i] = t[i];
+}
+static void invert_affine(const double* m, double* o) {
+    double D = m[0] * m[4] - m[1] * m[3];
+    D = D != 0 ? 1.0 / D : 0;
+    const double A11 = m[4] * D, A22 = m[0] * D, A12 = -m[1] * D, A21 = -m[3] * D;
+    o[0] = A11; o[1] = A12; o[2] = -A11 * m[2] - A12 * m[5];
+    o[3] = A21; o[4] = A22; o[5] = -A21 * m[2] - A22 * m[5];
+    o[6] = 0; o[7] = 0; o[8] = 1;
+}
+
+// Bring the frames of a stack into HBM (no copy when they already are).
+static stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<const void*>& dev) {
+    const size_t rb = frame_row_bytes(f), fb = rb * f->height;
+    dev.resize(f->n);
+    if (f->location == STK_DEVICE) { for (int i = 0; i < f->n; i++) dev[i] = f->data[i]; return STK_OK; }
+    HIP_TRY(ctx->frames.reserve(fb * f->n));
+    for (int i = 0; i < f->n; i++) {
+        void* d = ctx->frames.as<uint8_t>() + fb * i;
+        HIP_TRY(hipMemcpyAsync(d, f->data[i], fb, hipMemcpyHostToDevice, ctx->stream));
+        dev[i] = d;
+    }
+    return STK_OK;
+}
+
+static stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!f || f->n <= 0 || !f->data) return fail(ctx, STK_NOT_ENOUGH_FILES, "Not enough files");
+    if (f->width <= 0 || f->height <= 0) return fail(ctx, STK_INVALID_PARAMS, "bad frame geometry");
+    if (f->depth != 8 && f->depth != 16 && f->depth != 32) return fail(ctx, STK_INVALID_PARAMS, "depth must be 8, 16 or 32");
+    if (need_bgr && f->channels != 3)
+        return fail(ctx, STK_BACKEND_ERROR, "cvtColor(BGR2GRAY): frames must have 3 channels (utils.rs:136)");
+    if (f->channels != 1 && f->channels != 3) return fail(ctx, STK_INVALID_PARAMS, "channels must be 1 or 3");
+    if ((size_t)f->width * f->height > (size_t)1 << 30) return fail(ctx, STK_INVALID_PARAMS, "frame too large");
+    return STK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* stk_version(void) { return "libstacker_rs_amd 0.1 (gfx950)"; }
+
+stk_status stk_create(int32_t device_id, stk_ctx** out) {
+    if (!out) return STK_INVALID_PARAMS;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return STK_HIP_ERROR;
+    if (hipSetDevice(device_id) != hipSuccess) return STK_HIP_ERROR;
+    stk_ctx* ctx = new stk_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+    ctx->stream = ctx->own_stream;
+    for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+    for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+    if (hipHostMalloc((void**)&ctx->host_done, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+    ctx->kp = keypoint_workspace_create();
+    *out = ctx;
+    return STK_OK;
+}
+
+void stk_destroy(stk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->frames, &ctx->ref, &ctx->blur_tmp, &ctx->templates, &ctx->slots, &ctx->queue, &ctx->results,
+                      &ctx->partials, &ctx->warpframes, &ctx->acc, &ctx->scratch, &ctx->init_warps})
+        b->release();
+    keypoint_workspace_destroy(ctx->kp);
+    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->host_done) (void)hipHostFree(ctx->host_done);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* stk_last_error(const stk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+stk_status stk_set_stream(stk_ctx* ctx, void* hip_stream) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return STK_OK;
+}
+
+stk_status stk_get_timing(const stk_ctx* ctx, stk_timing* out) {
+    if (!ctx || !out) return STK_INVALID_PARAMS;
+    *out = ctx->timing;
+    return STK_OK;
+}
+
+stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return STK_INVALID_PARAMS;
+    const std::string n(name);
+    if (n == "ecc_slots") { if (value < 0 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_slots out of range"); ctx->opt_ecc_slots = (int)value; }
+    else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
+    else if (n == "profile") ctx->opt_profile = value != 0;
+    else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
+    else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
+    return STK_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// ECC machinery shared by stk_ecc_match_shard and stk_find_transform_ecc
+// ---------------------------------------------------------------------------------------------
+struct EccPlan {
+    int w, h, n_templates, motion;
+    int templ_row_stride;
+    size_t templ_plane_stride;
+    int ref_stride;
+    size_t ref_plane_floats;
+    int n_slots, nb, nsums;
+};
+
+static stk_status ecc_validate(stk_ctx* ctx, const stk_ecc_params* p, EccCriteria& crit) {
+    if (!p) return fail(ctx, STK_INVALID_PARAMS, "null params");
+    if (p->motion_type < 0 || p->motion_type > 3) return fail(ctx, STK_INVALID_PARAMS, "bad motion type");
+    // TermCriteria with neither COUNT nor EPS: OpenCV's CV_Assert fails -> OpenCvError (utils.rs:159-170)
+    if (!p->has_max_count && !p->has_epsilon)
+        return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: criteria needs COUNT and/or EPS");
+    if (p->has_max_count && p->max_count < 0) return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: maxCount < 0");
+    if (p->has_epsilon && p->epsilon < 0) return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: epsilon < 0");
+    if (p->gauss_filt_size <= 0 || p->gauss_filt_size % 2 == 0)
+        return fail(ctx, STK_BACKEND_ERROR, "GaussianBlur: kernel size must be odd and positive");
+    if (p->gauss_filt_size > 31) return fail(ctx, STK_NOT_IMPLEMENTED, "gauss_filt_size > 31 is not supported");
+    crit.n_iter = p->has_max_count ? p->max_count : 200;
+    crit.eps = p->has_epsilon ? p->epsilon : -1;
+    return STK_OK;
+}
+
+static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int motion, EccPlan& pl) {
+    pl.w = w; pl.h = h; pl.n_templates = n_templates; pl.motion = motion;
+    pl.templ_row_stride = (w + 3) & ~3;
+    pl.templ_plane_stride = (size_t)pl.templ_row_stride * h;
+    pl.ref_stride = (w + 2 * REF_PAD + 3) & ~3;
+    pl.ref_plane_floats = (size_t)pl.ref_stride * (h + 2 * REF_PAD);
+    const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
+    pl.nsums = ecc_nsums(P);
+    int slots = ctx->opt_ecc_slots;
+    if (slots <= 0) {
+        const double px = (double)w * h;
+        slots = (int)std::lround(4.0 * 8294400.0 / px);
+        slots = std::max(4, std::min(slots, 16));
+    }
+    pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
+    // blocks per slot: multiple of 8 (XCD-aware decode), each block = 4 waves = 4 rows per sweep
+    const int row_groups = (h + 3) / 4;
+    int nb = std::max(8, std::min(row_groups, 2048 / pl.n_slots));
+    nb = std::max(8, (nb / 8) * 8);
+    pl.nb = nb;
+    HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 3 * sizeof(float)));
+    HIP_TRY(ctx->blur_tmp.reserve(pl.templ_plane_stride * sizeof(float)));
+    HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1)));
+    HIP_TRY(ctx->slots.reserve(sizeof(EccSlot) * pl.n_slots));
+    HIP_TRY(ctx->queue.reserve(sizeof(EccQueue)));
+    HIP_TRY(ctx->results.reserve(sizeof(EccFrameResult) * std::max(n_templates, 1)));
+    HIP_TRY(ctx->partials.reserve(sizeof(double) * pl.n_slots * pl.nb * pl.nsums));
+    return STK_OK;
+}
+
+// frame-0 side: grey -> blur -> zero-padded I/gx/gy planes
+static stk_status ecc_prepare_reference(stk_ctx* ctx, const EccPlan& pl, const void* img, int depth, int cn,
+                                        size_t stride_bytes, int gauss) {
+    HIP_TRY(launch_grey_blur(img, depth, cn, pl.w, pl.h, stride_bytes, gauss, ctx->blur_tmp.as<float>(), pl.templ_row_stride, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->ref.p, 0, pl.ref_plane_floats * 3 * sizeof(float), ctx->stream));
+    float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
+    HIP_TRY(launch_ref_planes(ctx->blur_tmp.as<float>(), pl.templ_row_stride, pl.w, pl.h, base, base + pl.ref_plane_floats,
+                              base + 2 * pl.ref_plane_floats, pl.ref_stride, ctx->stream));
+    return STK_OK;
+}
+
+// run the device-side iteration queue to completion; results copied to `res`
+static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, const float* init_warps_dev,
+                          std::vector<EccFrameResult>& res) {
+    res.resize(pl.n_templates);
+    if (pl.n_templates == 0) return STK_OK;
+    EccIterArgs a{};
+    const float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
+    a.ref = RefPlanes{base, base + pl.ref_plane_floats, base + 2 * pl.ref_plane_floats, pl.ref_stride, pl.w, pl.h};
+    a.templates = ctx->templates.as<float>();
+    a.templ_plane_stride = pl.templ_plane_stride;
+    a.templ_row_stride = pl.templ_row_stride;
+    a.tw = pl.w; a.th = pl.h;
+    a.slots = ctx->slots.as<EccSlot>();
+    a.n_slots = pl.n_slots;
+    a.nb = pl.nb;
+    a.partials = ctx->partials.as<double>();
+    EccQueue* q = ctx->queue.as<EccQueue>();
+    EccFrameResult* r = ctx->results.as<EccFrameResult>();
+    HIP_TRY(launch_ecc_init(a.slots, a.n_slots, q, pl.n_templates, r, init_warps_dev, ctx->stream));
+    if (crit.n_iter >= 1) {
+        // Enqueue chunks of (iterate, solve) launches; keep two chunks in flight and poll the
+        // device-side completion counter behind each. Launches after completion are no-ops.
+        const int chunk = ctx->opt_ecc_chunk;
+        int inflight = 0, head = 0;
+        long long launched = 0;
+        const long long max_launches = (long long)crit.n_iter * pl.n_templates + 2 * chunk;
+        bool done = false;
+        ctx->host_done[0] = ctx->host_done[1] = 0;
+        while (!done) {
+            while (inflight < 2) {
+                for (int c = 0; c < chunk; c++) {
+                    HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->stream));
+                    HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
+                }
+                launched += chunk;
+                ctx->timing.ecc_iter_launches += chunk;
+                const int slot = (head + inflight) & 1;
+                HIP_TRY(hipMemcpyAsync(&ctx->host_done[slot], &q->frames_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipEventRecord(ctx->poll_ev[slot], ctx->stream));
+                inflight++;
+            }
+            HIP_TRY(hipEventSynchronize(ctx->poll_ev[head]));
+            if (ctx->host_done[head] >= pl.n_templates) done = true;
+            head ^= 1; inflight--;
+            if (!done && launched > max_launches)
+                return fail(ctx, STK_PROCESSING_ERROR, "ECC queue did not drain (internal error)");
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(res.data(), r, sizeof(EccFrameResult) * pl.n_templates, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (crit.n_iter < 1)
+        for (auto& e : res) { for (int k = 0; k < 9; k++) e.warp[k] = (k % 4 == 0) ? 1.f : 0.f; e.iters = 0; e.status = 0; e.rho = -1; }
+    for (auto& e : res) ctx->timing.ecc_slot_iterations += e.iters;
+    return STK_OK;
+}
+
+static const char* ecc_status_message(int st) {
+    switch (st) {
+        case 1: return "findTransformECC: NaN encountered (StsNoConv)";
+        case 2: return "findTransformECC: the algorithm stopped before its convergence; the correlation is going to be minimized (StsNoConv)";
+        default: return "findTransformECC: frame was not processed";
+    }
+}
+
+// fold frames into `sum` (device, tightly packed or strided) through their warps
+static stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
+                            size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
+                            int is_affine, float* acc, size_t acc_stride_floats, int accumulate) {
+    if (wf.empty()) return STK_OK;
+    HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * wf.size()));
+    HIP_TRY(hipMemcpyAsync(ctx->warpframes.p, wf.data(), sizeof(WarpFrame) * wf.size(), hipMemcpyHostToDevice, ctx->stream));
+    WarpArgs a{};
+    a.frames = ctx->warpframes.as<WarpFrame>();
+    a.n_frames = (int)wf.size();
+    a.sw = w; a.sh = h; a.cn = cn;
+    a.src_stride = src_row_bytes / (depth / 8);
+    a.alpha = (float)alpha;
+    a.border_mode = border_mode;
+    for (int c = 0; c < 4; c++) a.bv[c] = border_value ? (float)border_value[c] : 0.f;
+    a.acc = acc; a.dw = w; a.dh = h; a.acc_stride = acc_stride_floats;
+    a.accumulate = accumulate; a.is_affine = is_affine; a.subpixel_bits = ctx->opt_subpixel_bits;
+    HIP_TRY(launch_warp_accumulate(a, depth, ctx->stream));
+    // the host vector may die before the copy above ran if the caller does not synchronise
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->timing.warp_launches += 1;
+    ctx->timing.warp_frames += (int64_t)wf.size();
+    return STK_OK;
+}
+
+static void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine) {
+    double inv[9];
+    if (is_affine) invert_affine(M, inv); else invert3x3(M, inv);
+    wf.src = src;
+    for (int k = 0; k < 9; k++) { wf.Md[k] = inv[k]; wf.M[k] = (float)inv[k]; }
+}
+
+static stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c) {
+    if (!im || !im->data) return fail(ctx, STK_INVALID_PARAMS, "null output image");
+    if (im->width != w || im->height != h || im->channels != c) return fail(ctx, STK_INVALID_PARAMS, "output image geometry mismatch");
+    if (im->row_stride_bytes && im->row_stride_bytes % 4) return fail(ctx, STK_INVALID_PARAMS, "output stride must be a multiple of 4");
+    return STK_OK;
+}
+static size_t image_stride_floats(const stk_image_f32* im) {
+    return im->row_stride_bytes ? im->row_stride_bytes / 4 : (size_t)im->width * im->channels;
+}
+
+static void timing_begin(stk_ctx* ctx) { std::memset(&ctx->timing, 0, sizeof(ctx->timing)); }
+static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+
+extern "C" {
+
+stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params,
+                               float scale_down_width, int32_t add_reference, stk_image_f32* sum,
+                               int32_t* n_added, stk_frame_stats* stats) {
+    stk_status st = check_frames(ctx, frames, true);
+    if (st) return st;
+    (void)hipSetDevice(ctx->device);
+    EccCriteria crit{};
+    if ((st = ecc_validate(ctx, params, crit))) return st;
+    if (frames->depth == 16)  // findTransformECC accepts CV_8UC1 / CV_32FC1 only
+        return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: 16-bit images are not supported (8UC1 or 32FC1 only)");
+    if (scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "ecc_match with scale_down_width (lib.rs:849) is not implemented yet");
+    const int w = frames->width, h = frames->height, n = frames->n;
+    if ((st = image_check(ctx, sum, w, h, 3))) return st;
+    if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
+    timing_begin(ctx);
+
+    std::vector<const void*> dev;
+    if ((st = resolve_frames(ctx, frames, dev))) return st;
+    const size_t rb = frame_row_bytes(frames);
+    EccPlan pl{};
+    if ((st = ecc_plan(ctx, w, h, n - 1, params->motion_type, pl))) return st;
+
+    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    if ((st = ecc_prepare_reference(ctx, pl, dev[0], frames->depth, 3, rb, params->gauss_filt_size))) return st;
+    for (int i = 1; i < n; i++)
+        HIP_TRY(launch_grey_blur(dev[i], frames->depth, 3, w, h, rb, params->gauss_filt_size,
+                                 ctx->templates.as<float>() + pl.templ_plane_stride * (i - 1), pl.templ_row_stride, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    std::vector<EccFrameResult> res;
+    if ((st = ecc_run(ctx, pl, crit, nullptr, res))) return st;
+    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+
+    const int is_affine = params->motion_type != STK_MOTION_HOMOGRAPHY;
+    int first_err = -1;
+    if (stats) {
+        std::memset(stats, 0, sizeof(stk_frame_stats) * n);
+        stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1;
+        stats[0].rho = 1;
+    }
+    for (int i = 1; i < n; i++) {
+        const EccFrameResult& e = res[i - 1];
+        if (stats) {
+            stats[i].status = e.status ? 2 : 0; stats[i].iterations = e.iters; stats[i].rho = e.rho;
+            for (int k = 0; k < 9; k++) stats[i].warp[k] = e.warp[k];
+            if (is_affine) { stats[i].warp[6] = 0; stats[i].warp[7] = 0; stats[i].warp[8] = 1; }
+        }
+        if (e.status && first_err < 0) first_err = i;
+    }
+    if (first_err >= 0)  // `?` at lib.rs:777: any OpenCV error aborts the whole stack
+        return fail(ctx, STK_BACKEND_ERROR, std::string(ecc_status_message(res[first_err - 1].status)) + " [frame " + std::to_string(first_err) + "]");
+
+    std::vector<WarpFrame> wf;
+    wf.reserve(n);
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (add_reference) { wf.emplace_back(); make_warp_frame(wf.back(), dev[0], I3, is_affine); }
+    for (int i = 1; i < n; i++) {
+        double M[9];
+        for (int k = 0; k < 9; k++) M[k] = res[i - 1].warp[k];
+        if (is_affine) { M[6] = 0; M[7] = 0; M[8] = 1; }
+        wf.emplace_back();
+        make_warp_frame(wf.back(), dev[i], M, is_affine);
+    }
+    if (wf.empty()) HIP_TRY(hipMemsetAsync(sum->data, 0, image_stride_floats(sum) * h * sizeof(float), ctx->stream));
+    if ((st = warp_fold(ctx, wf, frames->depth, w, h, 3, rb, 1.0 / 255.0, STK_BORDER_CONSTANT, nullptr, is_affine,
+                        sum->data, image_stride_floats(sum), 0))) return st;
+    HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->timing.prep_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    ctx->timing.align_ms = ev_ms(ctx->ev[1], ctx->ev[2]);
+    ctx->timing.warp_ms = ev_ms(ctx->ev[2], ctx->ev[3]);
+    if (n_added) *n_added = (int32_t)wf.size();
+    return STK_OK;
+}
+
+stk_status stk_finalize_mean(stk_ctx* ctx, const stk_image_f32* sum, int64_t n_frames, stk_image_f32* out) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!sum || !out || !sum->data || !out->data) return fail(ctx, STK_INVALID_PARAMS, "null image");
+    if (n_frames <= 0) return fail(ctx, STK_INVALID_PARAMS, "All images discarded");   // lib.rs:324
+    if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "sum must be device memory");
+    if (sum->row_stride_bytes || out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "finalize expects tightly packed images");
+    (void)hipSetDevice(ctx->device);
+    const size_t n = (size_t)sum->width * sum->height * sum->channels;
+    const float sc = (float)(1.0 / (double)n_frames);   // MatExpr A / s == A.convertTo(-1, 1/s)
+    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+    if (out->location == STK_DEVICE) {
+        HIP_TRY(launch_scale(sum->data, out->data, n, sc, ctx->stream));
+    } else {
+        HIP_TRY(ctx->scratch.reserve(n * sizeof(float)));
+        HIP_TRY(launch_scale(sum->data, ctx->scratch.as<float>(), n, sc, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out->data, ctx->scratch.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->timing.finalize_ms = ev_ms(ctx->ev[4], ctx->ev[5]);
+    return STK_OK;
+}
+
+stk_status stk_ecc_match(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params,
+                         float scale_down_width, stk_image_f32* out, stk_frame_stats* stats) {
+    stk_status st = check_frames(ctx, frames, true);
+    if (st) return st;
+    if ((st = image_check(ctx, out, frames->width, frames->height, 3))) return st;
+    if (out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "output must be tightly packed");
+    (void)hipSetDevice(ctx->device);
+    const size_t nel = (size_t)frames->width * frames->height * 3;
+    stk_image_f32 sum = *out;
+    if (out->location != STK_DEVICE) {
+        HIP_TRY(ctx->acc.reserve(nel * sizeof(float)));
+        sum.data = ctx->acc.as<float>(); sum.location = STK_DEVICE;
+    }
+    int32_t added = 0;
+    if ((st = stk_ecc_match_shard(ctx, frames, params, scale_down_width, 1, &sum, &added, stats))) return st;
+    const stk_timing keep = ctx->timing;
+    st = stk_finalize_mean(ctx, &sum, frames->n, out);     // lib.rs:836-839: divide by files_vec.len()
+    const double fin = ctx->timing.finalize_ms;
+    ctx->timing = keep; ctx->timing.finalize_ms = fin;
+    return st;
+}
+
+// ---- stage-level entry points ------------------------------------------------------------------
+stk_status stk_grey(stk_ctx* ctx, const stk_frames* f, void* out) {
+    stk_status st = check_frames(ctx, f, true);
+    if (st) return st;
+    if (!out) return fail(ctx, STK_INVALID_PARAMS, "null output");
+    (void)hipSetDevice(ctx->device);
+    std::vector<const void*> dev;
+    if ((st = resolve_frames(ctx, f, dev))) return st;
+    const size_t ob = (size_t)f->width * f->height * (f->depth / 8);
+    void* d = out;
+    if (f->location == STK_HOST) { HIP_TRY(ctx->scratch.reserve(ob)); d = ctx->scratch.p; }
+    HIP_TRY(launch_grey(dev[0], f->depth, f->width, f->height, frame_row_bytes(f), d, ctx->stream));
+    if (f->location == STK_HOST) HIP_TRY(hipMemcpyAsync(out, d, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+stk_status stk_convert_f32(stk_ctx* ctx, const stk_frames* f, double alpha, float* out) {
+    stk_status st = check_frames(ctx, f, false);
+    if (st) return st;
+    if (!out) return fail(ctx, STK_INVALID_PARAMS, "null output");
+    if (f->row_stride_bytes && f->row_stride_bytes != (size_t)f->width * f->channels * (f->depth / 8))
+        return fail(ctx, STK_INVALID_PARAMS, "convert expects tightly packed frames");
+    (void)hipSetDevice(ctx->device);
+    std::vector<const void*> dev;
+    if ((st = resolve_frames(ctx, f, dev))) return st;
+    const size_t n = (size_t)f->width * f->height * f->channels;
+    float* d = out;
+    if (f->location == STK_HOST) { HIP_TRY(ctx->scratch.reserve(n * 4)); d = ctx->scratch.as<float>(); }
+    HIP_TRY(launch_convert_f32(dev[0], f->depth, n, (float)alpha, d, ctx->stream));
+    if (f->location == STK_HOST) HIP_TRY(hipMemcpyAsync(out, d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+stk_status stk_gaussian_blur_f32(stk_ctx* ctx, const void* grey, int32_t depth, int32_t width, int32_t height,
+                                 int32_t location, int32_t ksize, float* out) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!grey || !out || width <= 0 || height <= 0) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
+    if (depth != 8 && depth != 32) return fail(ctx, STK_INVALID_PARAMS, "blur input must be u8 or f32");
+    if (ksize <= 0 || ksize % 2 == 0) return fail(ctx, STK_BACKEND_ERROR, "GaussianBlur: kernel size must be odd and positive");
+    if (ksize > 31) return fail(ctx, STK_NOT_IMPLEMENTED, "ksize > 31 is not supported");
+    (void)hipSetDevice(ctx->device);
+    const size_t ib = (size_t)width * height * (depth / 8), ob = (size_t)width * height * 4;
+    const void* src = grey; float* dst = out;
+    if (location == STK_HOST) {
+        HIP_TRY(ctx->frames.reserve(ib)); HIP_TRY(ctx->scratch.reserve(ob));
+        HIP_TRY(hipMemcpyAsync(ctx->frames.p, grey, ib, hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->frames.p; dst = ctx->scratch.as<float>();
+    }
+    HIP_TRY(launch_grey_blur(src, depth, 1, width, height, (size_t)width * (depth / 8), ksize, dst, width, ctx->stream));
+    if (location == STK_HOST) HIP_TRY(hipMemcpyAsync(out, dst, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* input, int32_t depth, int32_t width,
+                                  int32_t height, int32_t location, const stk_ecc_params* params, float* warp,
+                                  double* rho, int32_t* iterations) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!templ || !input || !warp || width <= 0 || height <= 0) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
+    if (depth != 8 && depth != 32) return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: images must be 8UC1 or 32FC1");
+    EccCriteria crit{};
+    stk_status st = ecc_validate(ctx, params, crit);
+    if (st) return st;
+    (void)hipSetDevice(ctx->device);
+    timing_begin(ctx);
+    const size_t ib = (size_t)width * height * (depth / 8);
+    const void* t = templ; const void* in = input;
+    if (location == STK_HOST) {
+        HIP_TRY(ctx->frames.reserve(2 * ib));
+        HIP_TRY(hipMemcpyAsync(ctx->frames.p, templ, ib, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->frames.as<uint8_t>() + ib, input, ib, hipMemcpyHostToDevice, ctx->stream));
+        t = ctx->frames.p; in = ctx->frames.as<uint8_t>() + ib;
+    }
+    EccPlan pl{};
+    const int saved_slots = ctx->opt_ecc_slots;
+    if ((st = ecc_plan(ctx, width, height, 1, params->motion_type, pl))) return st;
+    (void)saved_slots;
+    const size_t rb = (size_t)width * (depth / 8);
+    if ((st = ecc_prepare_reference(ctx, pl, in, depth, 1, rb, params->gauss_filt_size))) return st;
+    HIP_TRY(launch_grey_blur(t, depth, 1, width, height, rb, params->gauss_filt_size, ctx->templates.as<float>(), pl.templ_row_stride, ctx->stream));
+    float w9[9];
+    for (int k = 0; k < 9; k++) w9[k] = warp[k];
+    if (params->motion_type != STK_MOTION_HOMOGRAPHY) { w9[6] = 0; w9[7] = 0; w9[8] = 1; }
+    HIP_TRY(ctx->init_warps.reserve(sizeof(w9)));
+    HIP_TRY(hipMemcpyAsync(ctx->init_warps.p, w9, sizeof(w9), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<EccFrameResult> res;
+    if ((st = ecc_run(ctx, pl, crit, ctx->init_warps.as<float>(), res))) return st;
+    if (crit.n_iter >= 1) for (int k = 0; k < 9; k++) warp[k] = res[0].warp[k];
+    if (rho) *rho = res[0].rho;
+    if (iterations) *iterations = res[0].iters;
+    if (res[0].status) return fail(ctx, STK_BACKEND_ERROR, ecc_status_message(res[0].status));
+    return STK_OK;
+}
+
+stk_status stk_warp_accumulate(stk_ctx* ctx, const stk_frames* f, const double* M, int32_t is_affine, int32_t border_mode,
+                               const double* border_value, double alpha, int32_t accumulate, stk_image_f32* acc) {
+    stk_status st = check_frames(ctx, f, false);
+    if (st) return st;
+    if (!M) return fail(ctx, STK_INVALID_PARAMS, "null matrix");
+    if (border_mode < 0 || border_mode > 4)
+        return fail(ctx, border_mode == STK_BORDER_TRANSPARENT ? STK_NOT_IMPLEMENTED : STK_INVALID_PARAMS,
+                    "border mode not supported (BORDER_TRANSPARENT leaves the reference's output uninitialised)");
+    if ((st = image_check(ctx, acc, f->width, f->height, f->channels))) return st;
+    (void)hipSetDevice(ctx->device);
+    std::vector<const void*> dev;
+    if ((st = resolve_frames(ctx, f, dev))) return st;
+    const size_t nel = (size_t)f->width * f->height * f->channels;
+    float* d = acc->data; size_t stride = image_stride_floats(acc);
+    if (acc->location == STK_HOST) {
+        if (acc->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "host accumulator must be tightly packed");
+        HIP_TRY(ctx->acc.reserve(nel * 4));
+        d = ctx->acc.as<float>();
+        if (accumulate) HIP_TRY(hipMemcpyAsync(d, acc->data, nel * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    std::vector<WarpFrame> wf(1);
+    make_warp_frame(wf[0], dev[0], M, is_affine);
+    if ((st = warp_fold(ctx, wf, f->depth, f->width, f->height, f->channels, frame_row_bytes(f), alpha, border_mode,
+                        border_value, is_affine, d, stride, accumulate))) return st;
+    if (acc->location == STK_HOST) HIP_TRY(hipMemcpyAsync(acc->data, d, nel * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+"""GPU parity of findTransformECC / ecc_match against the CPU oracle and the generator's ground truth."""
+import numpy as np
+import pytest
+
+import oracle
+from libstacker_rs_amd import EccMatchParameters, MotionType, OpenCvError, NotEnoughFiles, synth
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)     # examples/main.rs:107-112
+
+
+def test_find_transform_ecc_homography_matches_oracle(stacker, small_stack):
+    frames, G = small_stack
+    g0 = oracle.grey(frames[0])
+    for i in range(1, len(frames)):
+        gi = oracle.grey(frames[i])
+        W, rho, its = stacker.find_transform_ecc(gi, g0, np.eye(3), PARAMS)
+        rc, Wo, rho_o, its_o = oracle.find_transform_ecc(gi, g0, np.eye(3), oracle.MOTION_HOMOGRAPHY, 5000, 1e-5, 5)
+        assert rc == 0
+        # <= 0.05 px corner displacement vs the oracle, iteration count within +-1
+        assert synth.corner_error(W, Wo, 320, 240) <= 0.05
+        assert abs(its - its_o) <= 1
+        assert abs(rho - rho_o) <= 1e-5
+        assert synth.corner_error(W, G[i], 320, 240) <= 0.25      # vs generator ground truth
+
+
+@pytest.mark.parametrize("motion,omotion", [(MotionType.Translation, oracle.MOTION_TRANSLATION),
+                                            (MotionType.Euclidean, oracle.MOTION_EUCLIDEAN),
+                                            (MotionType.Affine, oracle.MOTION_AFFINE)])
+def test_find_transform_ecc_other_motions(stacker, small_stack, motion, omotion):
+    frames, _ = small_stack
+    g0, g1 = oracle.grey(frames[0]), oracle.grey(frames[1])
+    p = EccMatchParameters(motion, 200, 1e-6, 3)
+    W, rho, its = stacker.find_transform_ecc(g1, g0, np.eye(2, 3), p)
+    rc, Wo, rho_o, its_o = oracle.find_transform_ecc(g1, g0, np.eye(2, 3), omotion, 200, 1e-6, 3)
+    assert rc == 0
+    assert synth.corner_error(W, Wo, 320, 240) <= 0.05
+    assert abs(rho - rho_o) <= 1e-5
+
+
+def test_fixed_iteration_count_no_eps(stacker, small_stack):
+    frames, _ = small_stack
+    g0, g1 = oracle.grey(frames[0]), oracle.grey(frames[2])
+    p = EccMatchParameters(MotionType.Homography, 3, None, 5)
+    W, rho, its = stacker.find_transform_ecc(g1, g0, np.eye(3), p)
+    rc, Wo, rho_o, its_o = oracle.find_transform_ecc(g1, g0, np.eye(3), oracle.MOTION_HOMOGRAPHY, 3, None, 5)
+    assert its == 3 and its_o == 3
+    assert synth.corner_error(W, Wo, 320, 240) <= 0.01
+    # per-iteration agreement is much tighter than at an eps-terminated stop
+    np.testing.assert_allclose(W, Wo, rtol=0, atol=2e-5)
+
+
+def test_translated_pattern_recovers_shift(stacker):
+    # closed-form known answer: smooth pattern shifted by (3, -2) px
+    yy, xx = np.mgrid[0:200, 0:260].astype(np.float64)
+    def pat(x, y):
+        return 120 + 60 * np.sin(x / 9.0) * np.cos(y / 7.0) + 40 * np.sin((x + 2 * y) / 23.0)
+    ref = np.clip(pat(xx, yy), 0, 255).astype(np.uint8)
+    mov = np.clip(pat(xx + 3.0, yy - 2.0), 0, 255).astype(np.uint8)    # mov(x) = ref(x + (3,-2))
+    p = EccMatchParameters(MotionType.Translation, 300, 1e-8, 5)
+    W, rho, its = stacker.find_transform_ecc(mov, ref, np.eye(2, 3), p)
+    assert abs(W[0, 2] - 3.0) < 0.03 and abs(W[1, 2] + 2.0) < 0.03
+    assert rho > 0.999
+
+
+def test_uncorrelated_images_raise_opencv_error(stacker):
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    b = np.full((64, 64), 7, np.uint8)                       # constant input: zero variance -> NaN rho
+    with pytest.raises(OpenCvError):
+        stacker.find_transform_ecc(a, b, np.eye(3), PARAMS)
+    rc, *_ = oracle.find_transform_ecc(a, b, np.eye(3), oracle.MOTION_HOMOGRAPHY, 5000, 1e-5, 5)
+    assert rc != 0
+
+
+def test_criteria_without_count_or_eps_is_an_error(stacker, small_stack):
+    frames, _ = small_stack
+    with pytest.raises(OpenCvError):
+        stacker.ecc_match(list(frames), EccMatchParameters(MotionType.Homography, None, None, 5))
+
+
+def test_ecc_match_empty_list(stacker):
+    with pytest.raises(NotEnoughFiles):
+        stacker.ecc_match([], PARAMS)
+
+
+def test_ecc_match_stack_matches_oracle(stacker, small_stack):
+    frames, G = small_stack
+    out, stats = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
+    ref, warps, iters = oracle.ecc_match(list(frames), max_count=5000, epsilon=1e-5, gauss_filt_size=5)
+    for i in range(1, len(frames)):
+        assert synth.corner_error(stats[i]["warp"], warps[i], 320, 240) <= 0.05
+        assert synth.corner_error(stats[i]["warp"], G[i], 320, 240) <= 0.25
+    # stacked output: a 0.05-px warp difference moves edge pixels slightly; compare robustly and exactly:
+    rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert np.percentile(rel[4:-4, 4:-4], 99.5) < 2e-3
+    # given the oracle's warps, the fold itself is exact to f32 round-off (<= 1e-6 per frame)
+    acc = None
+    for i, f in enumerate(frames):
+        M = np.eye(3) if i == 0 else warps[i].astype(np.float64)
+        acc = stacker.warp_accumulate(f, M, acc=acc)
+    got = acc * np.float32(1.0 / len(frames))
+    assert np.max(np.abs(got - ref)) <= 1e-4 * np.max(np.abs(ref))      # north-star tolerance
+    assert np.max(np.abs(got - ref)) <= 4e-6
+
+
+def test_ecc_match_single_frame_is_convert(stacker, small_stack):
+    frames, _ = small_stack
+    out = stacker.ecc_match([frames[0]], PARAMS)
+    assert np.array_equal(out, oracle.convert_f32(frames[0]))
+
+
+def test_ecc_match_device_resident_equals_host_fed(stacker, small_stack):
+    import torch
+    frames, _ = small_stack
+    host = stacker.ecc_match(list(frames), PARAMS)
+    dev = stacker.ecc_match(torch.from_numpy(frames).cuda(), PARAMS)
+    assert np.array_equal(dev.cpu().numpy(), host)              # deterministic: fixed reduction order
+
+
+def test_slot_count_does_not_change_results(stacker, small_stack):
+    frames, _ = small_stack
+    base, s0 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
+    for slots in (1, 2, 3):
+        stacker.set_option("ecc_slots", slots)
+        try:
+            out, s1 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
+        finally:
+            stacker.set_option("ecc_slots", 0)
+        assert np.array_equal(out, base)
+        assert [s["iterations"] for s in s1] == [s["iterations"] for s in s0]

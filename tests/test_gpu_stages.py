@@ -1,0 +1,132 @@
+"""GPU parity of the per-pixel stages against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng_img(h, w, c, dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    if dtype == np.uint8:
+        return rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    if dtype == np.uint16:
+        return rng.integers(0, 65536, (h, w, c), dtype=np.uint16)
+    return rng.random((h, w, c), dtype=np.float32)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_grey_bit_exact(stacker, dtype):
+    img = _rng_img(97, 131, 3, dtype)
+    got = stacker.grey(img)
+    ref = oracle.grey(img)
+    assert got.dtype == ref.dtype
+    assert np.array_equal(got, ref)          # integer formula: bit exact; f32: same three roundings
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_convert_bit_exact(stacker, dtype):
+    img = _rng_img(64, 80, 3, dtype, 1)
+    assert np.array_equal(stacker.convert_f32(img), oracle.convert_f32(img))
+
+
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7])
+def test_gaussian_blur_small_kernels_bit_exact(stacker, ksize):
+    # dyadic taps on u8 input: every partial sum is exactly representable, so any order agrees
+    g = _rng_img(150, 201, 1, np.uint8, 2)[..., 0]
+    assert np.array_equal(stacker.gaussian_blur_f32(g, ksize), oracle.gaussian_blur_f32(g, ksize))
+
+
+@pytest.mark.parametrize("ksize", [9, 15, 31])
+def test_gaussian_blur_large_kernels(stacker, ksize):
+    g = _rng_img(90, 140, 1, np.uint8, 3)[..., 0]
+    got, ref = stacker.gaussian_blur_f32(g, ksize), oracle.gaussian_blur_f32(g, ksize)
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-4)
+
+
+def test_gaussian_blur_tiny_image_reflects(stacker):
+    g = _rng_img(3, 5, 1, np.uint8, 4)[..., 0]
+    assert np.array_equal(stacker.gaussian_blur_f32(g, 7), oracle.gaussian_blur_f32(g, 7))
+
+
+H_CASES = {
+    "identity": np.eye(3),
+    "shift_int": np.array([[1, 0, 5], [0, 1, -3], [0, 0, 1.0]]),
+    "shift_frac": np.array([[1, 0, 2.25], [0, 1, 1.5], [0, 0, 1.0]]),
+    "projective": np.array([[1.01, 0.02, -3.3], [-0.015, 0.99, 4.1], [2e-5, -1e-5, 1.0]]),
+    "big_rotation": np.array([[0.8, -0.6, 40.0], [0.6, 0.8, -30.0], [0, 0, 1.0]]),
+}
+
+
+@pytest.mark.parametrize("name", list(H_CASES))
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_warp_perspective_matches_oracle(stacker, name, dtype):
+    img = _rng_img(120, 160, 3, dtype, 5)
+    M = H_CASES[name]
+    got = stacker.warp_accumulate(img, M)
+    ref = oracle.warp_frame(img, M)
+    # identical f32 operation sequence (explicit fma, true division): <= 1e-6 abs
+    scale = 1.0 if dtype != np.uint16 else 257.0
+    assert np.max(np.abs(got - ref)) <= 1e-6 * scale
+
+
+def test_warp_identity_is_convert(stacker):
+    img = _rng_img(50, 70, 3, np.uint8, 6)
+    assert np.array_equal(stacker.warp_accumulate(img, np.eye(3)), oracle.convert_f32(img))
+
+
+def test_warp_integer_shift_is_shifted_copy(stacker):
+    img = _rng_img(40, 60, 3, np.uint8, 7)
+    M = np.array([[1, 0, 4], [0, 1, 2], [0, 0, 1.0]])       # frame_i -> frame_0: moves content by (+4,+2)
+    got = stacker.warp_accumulate(img, M)
+    ref = np.zeros((40, 60, 3), np.float32)
+    ref[2:, 4:] = oracle.convert_f32(img)[:-2, :-4]
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("mode", [oracle.BORDER_CONSTANT, oracle.BORDER_REPLICATE, oracle.BORDER_REFLECT,
+                                  oracle.BORDER_WRAP, oracle.BORDER_REFLECT_101])
+def test_warp_border_modes(stacker, mode):
+    img = _rng_img(64, 48, 3, np.uint8, 8)
+    M = np.array([[1.05, 0.1, -9.0], [-0.08, 0.97, 7.5], [1e-4, 5e-5, 1.0]])
+    bv = (0.25, 0.5, 0.75, 0)
+    got = stacker.warp_accumulate(img, M, border_mode=mode, border_value=bv)
+    ref = oracle.warp_frame(img, M, border_mode=mode, border_value=bv)
+    assert np.max(np.abs(got - ref)) <= 1e-6
+
+
+def test_warp_affine_and_accumulate(stacker):
+    img = _rng_img(72, 96, 3, np.uint8, 9)
+    M = np.array([[0.99, 0.03, 1.7], [-0.03, 1.01, -2.2]])
+    acc0 = np.random.default_rng(1).random((72, 96, 3), dtype=np.float32)
+    got = stacker.warp_accumulate(img, M, is_affine=True, acc=acc0.copy())
+    ref = oracle.warp_frame(img, M, is_affine=True, acc=acc0.copy())
+    assert np.max(np.abs(got - ref)) <= 1e-6
+
+
+def test_warp_single_channel(stacker):
+    img = _rng_img(33, 45, 1, np.float32, 10)
+    M = H_CASES["projective"]
+    got = stacker.warp_accumulate(img, M, alpha=1.0)
+    ref = oracle.warp_frame(img, M, alpha=1.0)
+    assert np.max(np.abs(got - ref)) <= 1e-6
+
+
+def test_warp_classic_quantised_mode(stacker):
+    img = _rng_img(80, 100, 3, np.uint8, 11)
+    M = H_CASES["projective"]
+    stacker.set_option("warp_subpixel_bits", 5)
+    try:
+        got = stacker.warp_accumulate(img, M)
+    finally:
+        stacker.set_option("warp_subpixel_bits", 0)
+    ref = oracle.warp_frame(img, M, subpixel_bits=5)
+    assert np.max(np.abs(got - ref)) <= 1e-6
+
+
+def test_warp_degenerate_matrix_gives_border(stacker):
+    img = _rng_img(16, 16, 3, np.uint8, 12)
+    got = stacker.warp_accumulate(img, np.zeros((3, 3)))       # singular: inverse is the zero matrix
+    ref = oracle.warp_frame(img, np.zeros((3, 3)))
+    assert np.array_equal(got, ref)
