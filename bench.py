@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec aligned+stacked on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over this rank's shard of a synthetic stack that is already
+resident in HBM: ecc_match (grey -> blur -> ECC homography, 5000 iters / eps 1e-5 / gauss 5, the
+reference example's parameters, examples/main.rs:107-112) -> warpPerspective -> f32 accumulate,
+then the cross-rank reduce of the accumulator (RCCL) and the final 1/n scale on rank 0.
+
+Default workload = BASELINE.json configs[3] cut to one GPU: 3840x2160 BGR u8, 32 frames per GPU
+(256 frames over 8 GPUs). Frames are sharded contiguously, one process per GPU, no data-path
+collective except the single accumulator reduce ("scaling": "weak").
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+WORKLOADS = {
+    # name: (width, height, frames per GPU, api)
+    "ecc_4k": (3840, 2160, 32, "ecc"),
+    "ecc_1080p": (1920, 1080, 64, "ecc"),
+    "keypoint_1080p": (1920, 1080, 64, "keypoint"),
+    "ecc_small": (640, 480, 8, "ecc"),
+}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ecc_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-per-gpu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = cores+1)")
+    ap.add_argument("--ecc-slots", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="engine tuning knob name=value (stk_set_option)")
+    ap.add_argument("--profile-launches", type=int, default=1,
+                    help="1: bracket every ECC iteration launch with HIP events (roofline.achieved); 0: off")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from libstacker_rs_amd import (EccMatchParameters, KeyPointMatchParameters, MotionType, RANSAC, Stacker, synth)
+
+    W, H, fpg, api = WORKLOADS[args.workload]
+    if args.frames_per_gpu > 0:
+        fpg = args.frames_per_gpu
+    n_global = fpg * world                       # frames in the whole stack (frame 0 = reference)
+    # contiguous shards of the moving frames 1..n-1; rank 0 also folds frame 0 itself in
+    moving = list(range(1, n_global))
+    per = [len(moving) // world + (1 if r < len(moving) % world else 0) for r in range(world)]
+    lo = sum(per[:rank])
+    mine = moving[lo:lo + per[rank]]
+
+    t0 = time.time()
+    scene = synth.render_scene(W, H)
+    frames, G = synth.make_stack(0, W, H, scene=scene, device=dev, indices=[0] + mine)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+
+    st = Stacker(local_rank)
+    st.use_torch_stream()
+    if args.ecc_slots:
+        st.set_option("ecc_slots", args.ecc_slots)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        st.set_option(k, int(v))
+    st.set_option("profile", 2 if args.profile_launches else 1)
+    ecc_params = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
+    kp_params = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
+    acc = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    out = torch.empty_like(acc)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    agg = {"ecc_iter_ms": 0.0, "ecc_iter_timed": 0, "ecc_slot_iterations": 0, "prep_ms": 0.0, "align_ms": 0.0,
+           "warp_ms": 0.0, "warp_frames": 0, "warp_launches": 0}
+    last_stats = None
+
+    def step(record: bool):
+        nonlocal last_stats
+        if api == "ecc":
+            added, stats = st.ecc_match_shard(frames, ecc_params, rank == 0, acc)
+            dropped = 0
+        else:
+            added, dropped, stats = st.keypoint_match_shard(frames, kp_params, rank == 0, acc)
+        if record:
+            t = st.timing()
+            for k in agg:
+                agg[k] += t[k]
+            last_stats = stats
+        counts[0] = added
+        counts[1] = dropped
+        if world > 1:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)          # RCCL over xGMI: the path's one exchange
+            dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.current_stream().synchronize()              # acc is rewritten by the next step
+        if rank == 0:
+            st.finalize_mean(acc, int(counts[0].item()), out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    frames_per_step = n_global
+    value = frames_per_step * args.steps / elapsed
+
+    if rank == 0:
+        px = W * H
+        res = {
+            "metric": "frames/sec aligned+stacked (4K RGB, ECC homography)" if args.workload == "ecc_4k"
+                      else f"frames/sec aligned+stacked ({args.workload})",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n_global}-frame {W}x{H} BGR u8 stack, "
+                                   + ("ecc_match Homography max_count 5000 eps 1e-5 gauss 5" if api == "ecc"
+                                      else "keypoint_match RANSAC thr 5.0 ratio 0.9 keep 0.80")
+                                   + f", {fpg} frames/GPU resident in HBM, frame-sharded, one accumulator reduce",
+                       "frames_per_gpu": fpg, "width": W, "height": H, "parallelism": f"frame-shard x{world}"},
+        }
+        # ---- roofline of the dominant kernel --------------------------------------------------
+        if api == "ecc" and agg["ecc_iter_timed"] > 0:
+            # ECC iteration kernel: ALGORITHMIC bytes = 16 B/px per frame-iteration (template 4 B +
+            # frame-0 image/gx/gy 12 B); one launch advances `slots` frames by one iteration.
+            alg_bytes_total = 16.0 * px * agg["ecc_slot_iterations"]
+            launches = agg["ecc_iter_timed"]
+            avg_ms = agg["ecc_iter_ms"] / launches
+            achieved = alg_bytes_total / (agg["ecc_iter_ms"] * 1e-3) / 1e9
+            res["roofline"] = {"kernel": "ecc_iter_kernel<HOMOGRAPHY>", "bound": "hbm", "achieved": round(achieved, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                               "traffic": None, "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                               "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
+        its = [s["iterations"] for s in (last_stats or [])[1:]]
+        src_b = 3 * px
+        warp_bytes = (agg["warp_frames"] * src_b + agg["warp_launches"] * 2 * 12 * px)
+        res["stages"] = {
+            "prep_ms_per_step": round(agg["prep_ms"] / args.steps, 3),
+            "align_ms_per_step": round(agg["align_ms"] / args.steps, 3),
+            "warp_ms_per_step": round(agg["warp_ms"] / args.steps, 3),
+            "ecc_iterations_mean": round(float(np.mean(its)), 2) if its else None,
+            "ecc_iterations_max": int(max(its)) if its else None,
+            "warp_accumulate_GBps_fused": round(warp_bytes / max(agg["warp_ms"], 1e-9) / 1e6, 1),
+            "warp_accumulate_GBps_survey_bytes": round(agg["warp_frames"] * (src_b + 24 * px) / max(agg["warp_ms"], 1e-9) / 1e6, 1),
+            "synthetic_generation_s": round(gen_s, 1),
+        }
+        # ---- CPU baseline: the oracle (a port of the reference's OpenCV/Rayon path) on host cores ----
+        if not args.no_cpu_baseline:
+            import oracle
+            cores = os.cpu_count() or 1
+            use = min(cores, 32)
+            n_s = args.cpu_sample_frames or (use + 1)
+            n_s = max(2, min(n_s, frames.shape[0]))
+            sample = [f.cpu().numpy() for f in frames[:n_s]]
+            tc = time.perf_counter()
+            if api == "ecc":
+                oracle.ecc_match(sample, max_count=5000, epsilon=1e-5, gauss_filt_size=5, n_threads=use)
+            else:
+                oracle.keypoint_match(sample, n_threads=use)
+            cpu_s = time.perf_counter() - tc
+            res["cpu_baseline"] = {"value": round(n_s / cpu_s, 4), "unit": "frames/s", "cores": use, "kind": "port",
+                                   "sample": f"first {n_s} frames of the same {W}x{H} stack, one oracle pass "
+                                             f"({cpu_s:.1f} s), frame-parallel OpenMP like the reference's Rayon fold"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,9 @@ typedef struct {
     int64_t ecc_slot_iterations;    /* sum over launches of active slots (frame-iterations) */
     int64_t warp_launches;
     int64_t warp_frames;
+    /* option "profile" = 2 brackets every ECC iteration launch with its own HIP event pair: */
+    double  ecc_iter_ms;            /* sum of those launch durations */
+    int64_t ecc_iter_timed;         /* number of launches measured */
 } stk_timing;
 
 typedef struct stk_ctx stk_ctx;

@@ -47,7 +47,7 @@ class Timing(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("align_ms", C.c_double), ("warp_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("ecc_iter_launches", C.c_int64),
                 ("ecc_slot_iterations", C.c_int64), ("warp_launches", C.c_int64),
-                ("warp_frames", C.c_int64)]
+                ("warp_frames", C.c_int64), ("ecc_iter_ms", C.c_double), ("ecc_iter_timed", C.c_int64)]
 
 
 # every symbol include/stacker.h declares, with its signature
@@ -96,6 +96,15 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C libstacker_rs_amd/csrc)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64
+        # and a second copy (from /opt/rocm) in the same process leaves whichever initialises last
+        # without a GPU. Importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to
+        # the copy torch already mapped, so tensors, streams and our kernels share one runtime.
+        # (Without torch installed the library binds to /opt/rocm through its RUNPATH.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pragma: no cover - torch is part of the target image
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the symbol is not exported

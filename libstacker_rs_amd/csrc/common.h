@@ -76,7 +76,7 @@ struct EccIterArgs {
     EccSlot* slots;
     int n_slots;
     int nb;                      // blocks per slot (multiple of 8)
-    double* partials;            // [n_slots][nb][nsums]
+    double* partials;            // [n_slots][nsums][nb]
 };
 
 struct WarpFrame {

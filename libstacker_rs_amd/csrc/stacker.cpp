@@ -38,10 +38,12 @@ struct stk_ctx {
     int opt_subpixel_bits = 0;
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
+    int opt_ecc_blocks = 1024;    // total workgroups of one ECC iteration launch (all slots)
     stk_timing timing{};
     hipEvent_t ev[8] = {};
     hipEvent_t poll_ev[2] = {};
     int* host_done = nullptr;     // pinned, 2 ints
+    std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
     KeypointWorkspace* kp = nullptr;
@@ -140,6 +142,7 @@ void stk_destroy(stk_ctx* ctx) {
     keypoint_workspace_destroy(ctx->kp);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->prof_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->host_done) (void)hipHostFree(ctx->host_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -164,13 +167,16 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "ecc_slots") { if (value < 0 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_slots out of range"); ctx->opt_ecc_slots = (int)value; }
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
-    else if (n == "profile") ctx->opt_profile = value != 0;
+    else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
+    else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;
 }
 
 }  // extern "C"
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 // ---------------------------------------------------------------------------------------------
 // ECC machinery shared by stk_ecc_match_shard and stk_find_transform_ecc
@@ -217,7 +223,7 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
     // blocks per slot: multiple of 8 (XCD-aware decode), each block = 4 waves = 4 rows per sweep
     const int row_groups = (h + 3) / 4;
-    int nb = std::max(8, std::min(row_groups, 2048 / pl.n_slots));
+    int nb = std::max(8, std::min(row_groups, ctx->opt_ecc_blocks / pl.n_slots));
     nb = std::max(8, (nb / 8) * 8);
     pl.nb = nb;
     HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 3 * sizeof(float)));
@@ -268,11 +274,19 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
         long long launched = 0;
         const long long max_launches = (long long)crit.n_iter * pl.n_templates + 2 * chunk;
         bool done = false;
+        size_t prof_used = 0;
+        if (ctx->opt_profile >= 2 && ctx->prof_ev.empty()) {
+            ctx->prof_ev.resize(8192);
+            for (auto& e : ctx->prof_ev) HIP_TRY(hipEventCreate(&e));
+        }
         ctx->host_done[0] = ctx->host_done[1] = 0;
         while (!done) {
             while (inflight < 2) {
                 for (int c = 0; c < chunk; c++) {
+                    const bool timed = ctx->opt_profile >= 2 && prof_used + 2 <= ctx->prof_ev.size();
+                    if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used], ctx->stream));
                     HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->stream));
+                    if (timed) { HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used + 1], ctx->stream)); prof_used += 2; }
                     HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
                 }
                 launched += chunk;
@@ -289,6 +303,10 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                 return fail(ctx, STK_PROCESSING_ERROR, "ECC queue did not drain (internal error)");
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i + 1 < prof_used; i += 2) {
+            ctx->timing.ecc_iter_ms += ev_ms(ctx->prof_ev[i], ctx->prof_ev[i + 1]);
+            ctx->timing.ecc_iter_timed += 1;
+        }
     }
     HIP_TRY(hipMemcpyAsync(res.data(), r, sizeof(EccFrameResult) * pl.n_templates, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -349,7 +367,6 @@ static size_t image_stride_floats(const stk_image_f32* im) {
 }
 
 static void timing_begin(stk_ctx* ctx) { std::memset(&ctx->timing, 0, sizeof(ctx->timing)); }
-static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 extern "C" {
 

@@ -85,10 +85,12 @@ def random_homography(rng: np.random.Generator, width: int, height: int, strengt
 
 
 def make_stack(n: int, width: int, height: int, *, seed: int = SEED, depth: int = 8, device="cpu",
-               noise_sigma: float = 2.0, strength: float = 1.0, scene: np.ndarray | None = None):
+               noise_sigma: float = 2.0, strength: float = 1.0, scene: np.ndarray | None = None,
+               indices=None):
     """Returns (frames, G): frames = torch uint8/int16-as-uint16 tensor [n,H,W,3] on `device`
     (BGR interleaved, the layout imread(UNCHANGED) yields, utils.rs:132), G = [n,3,3] float64
-    with frame_i(x) ~= frame_0(G_i x)."""
+    with frame_i(x) ~= frame_0(G_i x). `indices` selects global frame numbers (default 0..n-1), so a
+    rank can render just its slice of a larger stack; frame number 0 is always the unwarped scene."""
     import torch
     import torch.nn.functional as F
 
@@ -103,11 +105,14 @@ def make_stack(n: int, width: int, height: int, *, seed: int = SEED, depth: int 
     Gs = np.zeros((n, 3, 3), np.float64)
     frames = []
     gen = torch.Generator(device=dev)
-    for i in range(n):
+    indices = list(range(n)) if indices is None else list(indices)
+    n = len(indices)
+    Gs = np.zeros((n, 3, 3), np.float64)
+    for k, i in enumerate(indices):
         rng = np.random.Generator(np.random.PCG64(seed + 1 + i))
         G = np.eye(3) if i == 0 else random_homography(rng, width, height, strength)
         gain = 1.0 if i == 0 else rng.uniform(0.97, 1.03)
-        Gs[i] = G
+        Gs[k] = G
         g = torch.from_numpy(G).to(dev, fdt)
         den = g[2, 0] * xs + g[2, 1] * ys + g[2, 2]
         u = (g[0, 0] * xs + g[0, 1] * ys + g[0, 2]) / den + MARGIN

@@ -170,7 +170,7 @@ int orc_warp(const void* src, int depth, int sw, int sh, int cn, size_t src_stri
                 finite = std::isfinite(X) && std::isfinite(Y) && std::fabs(X) < 1e9f && std::fabs(Y) < 1e9f;
                 float flx = std::floor(X), fly = std::floor(Y);
                 ix = finite ? (int)flx : -100000; iy = finite ? (int)fly : -100000;
-                ax = X - flx; ay = Y - fly;
+                ax = finite ? X - flx : 0.f; ay = finite ? Y - fly : 0.f;
             } else {
                 const double S = 32.0;
                 double X, Y;
