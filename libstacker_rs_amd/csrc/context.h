@@ -1,0 +1,67 @@
+// context.h — the engine's per-GPU context (stk_ctx) and host helpers shared by stacker.cpp and keypoint.cpp.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "keypoint.h"
+
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + (bytes >> 3);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct stk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    int opt_ecc_slots = 0;        // 0 = auto
+    int opt_subpixel_bits = 0;
+    int opt_profile = 1;
+    int opt_ecc_chunk = 4;
+    int opt_ecc_blocks = 1024;    // total workgroups of one ECC iteration launch (all slots)
+    stk_timing timing{};
+    hipEvent_t ev[8] = {};
+    hipEvent_t poll_ev[2] = {};
+    int* host_done = nullptr;     // pinned, 2 ints
+    std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
+    // workspace
+    DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
+    stk::KeypointWorkspace* kp = nullptr;
+};
+
+inline stk_status fail(stk_ctx* ctx, stk_status st, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return st;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, STK_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+
+using stk::WarpFrame;
+size_t frame_row_bytes(const stk_frames* f);
+stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<const void*>& dev);
+stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr);
+stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
+                     size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
+                     int is_affine, float* acc, size_t acc_stride_floats, int accumulate);
+void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine);
+stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c);
+size_t image_stride_floats(const stk_image_f32* im);
+void timing_begin(stk_ctx* ctx);
+float ev_ms(hipEvent_t a, hipEvent_t b);

@@ -1,0 +1,267 @@
+// kernels_orb.hip — ORB::detect_and_compute (utils.rs:174-183) and the
+// brute-force Hamming 2-NN matcher (lib.rs:208-219; row C1) as gfx950 kernels. All integer / byte
+// work on 8-bit pyramids: HBM/L2-bound stencils, no MFMA.
+//
+//   resize_exact   INTER_LINEAR_EXACT 8-bit downscale (8.8 fixed-point coefficients, (v + 2^15) >> 16)
+//   fast_score     FAST-9/16 corner strength per pixel (0 = not a corner at the threshold)
+//   fast_nms       3x3 strict non-maximum suppression + runByImageBorder(31) + score histogram + collect
+//   fast_threshold per level: the score of the (2 n_l)-th best corner (retainBest keeps ties)
+//   fast_select    candidates >= threshold -> short list, with Harris response and the IC moments
+//   gauss7_rows/cols  GaussianBlur 7x7 sigma 2 (float separable filter, cvRound to u8)
+//   brief          rotated BRIEF, 256 tests, one lane per descriptor byte
+//   knn2_hamming   popcount(xor) over 32 B, two best train rows per query, ties keep the lower index
+#include "common.h"
+#include "keypoint.h"
+
+namespace stk {
+
+// ---- pyramid ------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_coef(int d, int src, double scale, int& ofs, int& c0, int& c1) {
+    const double fval = scale * ((double)d + 0.5) - 0.5;
+    const int ival = (int)floor(fval);
+    if (ival >= 0 && src > 1) {
+        if (ival < src - 1) { ofs = ival; c1 = (int)__builtin_rint((fval - (double)ival) * 256.0); c0 = 256 - c1; }
+        else { ofs = src - 1; c0 = 256; c1 = 0; }
+    } else { ofs = 0; c0 = 256; c1 = 0; }
+}
+
+__global__ __launch_bounds__(256) void resize_exact_kernel(const uint8_t* __restrict__ src, int sw, int sh,
+                                                           uint8_t* __restrict__ dst, int dw, int dh,
+                                                           double scale_x, double scale_y) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int ox, cx0, cx1, oy, cy0, cy1;
+    lin_coef(x, sw, scale_x, ox, cx0, cx1);
+    lin_coef(y, sh, scale_y, oy, cy0, cy1);
+    const int ox1 = min(ox + 1, sw - 1), oy1 = min(oy + 1, sh - 1);
+    const uint8_t* r0 = src + (size_t)oy * sw;
+    const uint8_t* r1 = src + (size_t)oy1 * sw;
+    const uint32_t h0 = (uint32_t)cx0 * r0[ox] + (uint32_t)cx1 * r0[ox1];
+    const uint32_t h1 = (uint32_t)cx0 * r1[ox] + (uint32_t)cx1 * r1[ox1];
+    const uint32_t v = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1;
+    dst[(size_t)y * dw + x] = (uint8_t)min((v + (1u << 15)) >> 16, 255u);
+}
+
+hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s) {
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
+    resize_exact_kernel<<<grid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, sx, sy);
+    return hipGetLastError();
+}
+
+// ---- FAST -----------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int stride, int thr) {
+    const int v = p[0];
+    // high-speed rejection: any 9 contiguous ring pixels contain at least two of the four compass points
+    const int n0 = v - p[3 * stride], n4 = v - p[3], n8 = v - p[-3 * stride], n12 = v - p[-3];
+    const int dark = (n0 > thr) + (n4 > thr) + (n8 > thr) + (n12 > thr);
+    const int bright = (n0 < -thr) + (n4 < -thr) + (n8 < -thr) + (n12 < -thr);
+    if (dark < 2 && bright < 2) return 0;
+    int d[16];
+    d[0] = n0;                       d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];   d[3] = v - p[stride + 3];
+    d[4] = n4;                       d[5] = v - p[-stride + 3];      d[6] = v - p[-2 * stride + 2];  d[7] = v - p[-3 * stride + 1];
+    d[8] = n8;                       d[9] = v - p[-3 * stride - 1];  d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
+    d[12] = n12;                     d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];  d[15] = v - p[3 * stride - 1];
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn = d[k], mx = d[k];
+#pragma unroll
+        for (int j = 1; j < 9; j++) { mn = min(mn, d[(k + j) & 15]); mx = max(mx, d[(k + j) & 15]); }
+        best = max(best, max(mn, -mx));
+    }
+    return best > thr ? best - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h, int thr,
+                                                         uint8_t* __restrict__ score) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    int s = 0;
+    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) s = fast_score_at(img + (size_t)y * w + x, w, thr);
+    score[(size_t)y * w + x] = (uint8_t)s;
+}
+
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, int w, int h, int edge,
+                                                       OrbLevelState* st, OrbCandidate* cand, int cap) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63) + edge, y = blockIdx.y * 4 + (threadIdx.x >> 6) + edge;
+    if (x >= w - edge || y >= h - edge) return;
+    const uint8_t* c = score + (size_t)y * w + x;
+    const int s = c[0];
+    if (!s) return;
+    if (s > c[-1] && s > c[1] && s > c[-w - 1] && s > c[-w] && s > c[-w + 1] && s > c[w - 1] && s > c[w] && s > c[w + 1]) {
+        atomicAdd(&st->hist[s], 1);
+        const int i = atomicAdd(&st->n_cand, 1);
+        if (i < cap) { cand[i].xy = x | (y << 16); cand[i].score = s; }
+    }
+}
+
+__global__ void fast_threshold_kernel(OrbLevelState* st, int keep) {
+    if (threadIdx.x != 0) return;
+    int cum = 0, thr = 1;
+    for (int s = 255; s >= 1; s--) {
+        cum += st->hist[s];
+        if (cum >= keep) { thr = s; break; }
+    }
+    st->threshold = keep > 0 ? thr : 256;
+    st->n_sel = 0;
+}
+
+// Harris response (blockSize 7, Sobel-like 3x3 on the 8-bit level, integer sums) and the IC moments
+__global__ __launch_bounds__(64) void fast_select_kernel(const uint8_t* __restrict__ img, int w, int h,
+                                                         OrbLevelState* st, const OrbCandidate* __restrict__ cand,
+                                                         int cap, OrbSelected* sel, int sel_cap, OrbUmax um) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int n = min(st->n_cand, cap);
+    if (i >= n) return;
+    const OrbCandidate c = cand[i];
+    if (c.score < st->threshold) return;
+    const int o = atomicAdd(&st->n_sel, 1);
+    if (o >= sel_cap) return;
+    const int x = c.xy & 0xffff, y = c.xy >> 16;
+    const uint8_t* p0 = img + (size_t)y * w + x;
+    int a = 0, b = 0, cc = 0;
+    for (int dy = -3; dy <= 3; dy++)
+        for (int dx = -3; dx <= 3; dx++) {
+            const uint8_t* p = p0 + dy * w + dx;
+            const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-w + 1] - (int)p[-w - 1]) + ((int)p[w + 1] - (int)p[w - 1]);
+            const int Iy = ((int)p[w] - (int)p[-w]) * 2 + ((int)p[w - 1] - (int)p[-w - 1]) + ((int)p[w + 1] - (int)p[-w + 1]);
+            a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
+        }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale4 = scale * scale * scale * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)cc;
+    const float resp = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale4;
+    int m01 = 0, m10 = 0;
+    for (int u = -15; u <= 15; u++) m10 += u * (int)p0[u];
+    for (int v = 1; v <= 15; v++) {
+        int vsum = 0;
+        const int d = um.u[v];
+        for (int u = -d; u <= d; u++) {
+            const int vp = p0[u + v * w], vm = p0[u - v * w];
+            vsum += vp - vm;
+            m10 += u * (vp + vm);
+        }
+        m01 += v * vsum;
+    }
+    OrbSelected s;
+    s.xy = c.xy; s.score = c.score; s.harris = resp; s.m01 = m01; s.m10 = m10;
+    sel[o] = s;
+}
+
+hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
+                             OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,
+                             const OrbUmax& um, hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    fast_score_kernel<<<grid, 256, 0, s>>>(img, w, h, thr, score);
+    if (w > 2 * edge && h > 2 * edge) {
+        dim3 g2((w - 2 * edge + 63) / 64, (h - 2 * edge + 3) / 4);
+        fast_nms_kernel<<<g2, 256, 0, s>>>(score, w, h, edge, st, cand, cap);
+    }
+    fast_threshold_kernel<<<1, 64, 0, s>>>(st, keep);
+    fast_select_kernel<<<(cap + 63) / 64, 64, 0, s>>>(img, w, h, st, cand, cap, sel, sel_cap, um);
+    return hipGetLastError();
+}
+
+// ---- 7x7 Gaussian on 8-bit levels -----------------------------------------------------------------------
+__device__ __forceinline__ int refl101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void gauss7_rows_kernel(const uint8_t* __restrict__ src, int w, int h, Gauss7 k,
+                                                          float* __restrict__ tmp) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const uint8_t* s = src + (size_t)y * w;
+    float acc = k.k[0] * (float)s[refl101(x - 3, w)];
+#pragma unroll
+    for (int i = 1; i < 7; i++) acc += k.k[i] * (float)s[refl101(x - 3 + i, w)];
+    tmp[(size_t)y * w + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void gauss7_cols_kernel(const float* __restrict__ tmp, int w, int h, Gauss7 k,
+                                                          uint8_t* __restrict__ dst) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    float acc = k.k[3] * tmp[(size_t)y * w + x];
+#pragma unroll
+    for (int i = 1; i <= 3; i++)
+        acc += k.k[3 + i] * (tmp[(size_t)refl101(y - i, h) * w + x] + tmp[(size_t)refl101(y + i, h) * w + x]);
+    const int r = (int)__builtin_rintf(acc);
+    dst[(size_t)y * w + x] = (uint8_t)min(max(r, 0), 255);
+}
+
+hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    gauss7_rows_kernel<<<grid, 256, 0, s>>>(src, w, h, k, tmp);
+    gauss7_cols_kernel<<<grid, 256, 0, s>>>(tmp, w, h, k, dst);
+    return hipGetLastError();
+}
+
+// ---- rotated BRIEF ------------------------------------------------------------------------------------
+__constant__ signed char c_orb_pattern[1024];
+
+hipError_t upload_orb_pattern(const signed char* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_orb_pattern), p, 1024);
+}
+
+// one lane per descriptor byte: grid = n_keypoints blocks of 32 threads
+__global__ __launch_bounds__(32) void brief_kernel(const uint8_t* __restrict__ pyr_blur, OrbPyramid pyr,
+                                                   const OrbFinalKeypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
+    const OrbFinalKeypoint kp = kps[blockIdx.x];
+    const int l = kp.level, w = pyr.w[l];
+    const uint8_t* center = pyr_blur + pyr.ofs[l] + (size_t)kp.cy * w + kp.cx;
+    const float a = kp.cos_a, b = kp.sin_a;
+    const int i = threadIdx.x;
+    int val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        const signed char* p = c_orb_pattern + (i * 8 + bit) * 4;
+        const float px0 = (float)p[0], py0 = (float)p[1], px1 = (float)p[2], py1 = (float)p[3];
+        const float x0 = px0 * a - py0 * b, y0 = px0 * b + py0 * a;
+        const float x1 = px1 * a - py1 * b, y1 = px1 * b + py1 * a;
+        const int t0 = center[(int)__builtin_rintf(y0) * w + (int)__builtin_rintf(x0)];
+        const int t1 = center[(int)__builtin_rintf(y1) * w + (int)__builtin_rintf(x1)];
+        val |= (t0 < t1) << bit;
+    }
+    desc[(size_t)blockIdx.x * 32 + i] = (uint8_t)val;
+}
+
+hipError_t launch_brief(const uint8_t* pyr_blur, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, uint8_t* desc,
+                        hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    brief_kernel<<<n, 32, 0, s>>>(pyr_blur, pyr, kps, desc);
+    return hipGetLastError();
+}
+
+// ---- brute-force Hamming 2-NN ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void knn2_hamming_kernel(const uint8_t* __restrict__ query, int nq,
+                                                          const uint8_t* __restrict__ train, int nt, int* __restrict__ out) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= nq) return;
+    const uint4* qa = reinterpret_cast<const uint4*>(query + (size_t)q * 32);
+    const uint4 q0 = qa[0], q1 = qa[1];
+    int i0 = -1, i1 = -1, d0 = 0x7fffffff, d1 = 0x7fffffff;
+    for (int t = 0; t < nt; t++) {
+        const uint4* ta = reinterpret_cast<const uint4*>(train + (size_t)t * 32);
+        const uint4 t0 = ta[0], t1 = ta[1];
+        const int d = __popc(q0.x ^ t0.x) + __popc(q0.y ^ t0.y) + __popc(q0.z ^ t0.z) + __popc(q0.w ^ t0.w) +
+                      __popc(q1.x ^ t1.x) + __popc(q1.y ^ t1.y) + __popc(q1.z ^ t1.z) + __popc(q1.w ^ t1.w);
+        if (d < d1) {                      // strict '<': ties keep the earlier (lower) train index
+            if (d < d0) { i1 = i0; d1 = d0; i0 = t; d0 = d; }
+            else { i1 = t; d1 = d; }
+        }
+    }
+    out[q * 4 + 0] = i0; out[q * 4 + 1] = i0 >= 0 ? d0 : -1;
+    out[q * 4 + 2] = i1; out[q * 4 + 3] = i1 >= 0 ? d1 : -1;
+}
+
+hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    knn2_hamming_kernel<<<(nq + 63) / 64, 64, 0, s>>>(query, nq, train, nt, out);
+    return hipGetLastError();
+}
+
+}  // namespace stk

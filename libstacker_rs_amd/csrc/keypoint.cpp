@@ -1,0 +1,422 @@
+// keypoint.cpp — keypoint_match (lib.rs:146-353) on the GPU engine: per frame ORB on device
+// (kernels_orb.hip) -> brute-force Hamming 2-NN on device -> Lowe ratio / stable sort / truncate and
+// RANSAC homography on the host (a few hundred points, homography.cpp) -> one fused
+// warpPerspective + accumulate launch over all kept frames (kernels_warp.hip).
+//
+// Drop semantics: the reference's `return Ok(None)` inside the Rayon fold wipes the segment
+// accumulator and never counts the drop, which makes its output schedule-dependent.
+// This implements the DOCUMENTED behaviour (lib.rs:98): a frame whose homography cannot be estimated
+// (<5 matches lib.rs:240, find_homography failure lib.rs:275, bad shape lib.rs:279, |det| < 1e-6
+// lib.rs:284) is skipped and counted; the sum is divided by n - dropped.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "context.h"
+#include "homography.h"
+#include "orb_pattern.h"
+
+using namespace stk;
+
+namespace stk {
+
+struct KeypointWorkspace {
+    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn;
+    bool pattern_uploaded = false;
+    OrbSelected* host_sel = nullptr;        // pinned
+    OrbLevelState* host_states = nullptr;   // pinned
+    int* host_knn = nullptr;                // pinned
+    size_t host_knn_cap = 0;
+};
+
+KeypointWorkspace* keypoint_workspace_create() { return new KeypointWorkspace(); }
+void keypoint_workspace_destroy(KeypointWorkspace* k) {
+    if (!k) return;
+    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn})
+        b->release();
+    if (k->host_sel) (void)hipHostFree(k->host_sel);
+    if (k->host_states) (void)hipHostFree(k->host_states);
+    if (k->host_knn) (void)hipHostFree(k->host_knn);
+    delete k;
+}
+
+}  // namespace stk
+
+namespace {
+
+inline int cv_round_f(float v) { return (int)std::lrintf(v); }
+inline int cv_round_d(double v) { return (int)std::lrint(v); }
+inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+
+// cv::fastAtan2 (degrees)
+float fast_atan2(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+struct HostKeypoint { float x, y, size, angle, response; int octave; int lx, ly; };
+
+struct OrbGeometry {
+    OrbPyramid pyr;
+    float scale[ORB_LEVELS];
+    int nfeatures[ORB_LEVELS];
+    OrbUmax umax;
+    Gauss7 g7;
+    size_t cand_ofs[ORB_LEVELS], cand_cap[ORB_LEVELS], cand_total;
+};
+
+void orb_geometry(int w, int h, OrbGeometry& g) {
+    size_t ofs = 0, cofs = 0;
+    for (int l = 0; l < ORB_LEVELS; l++) {
+        const float scale = (float)std::pow((double)1.2f, (double)l);      // getScale(level, 0, 1.2f)
+        const float inv = 1.0f / scale;
+        g.scale[l] = scale;
+        g.pyr.w[l] = cv_round_f((float)w * inv); g.pyr.h[l] = cv_round_f((float)h * inv);
+        g.pyr.ofs[l] = ofs;
+        ofs += ((size_t)g.pyr.w[l] * g.pyr.h[l] + 255) & ~(size_t)255;
+        g.cand_ofs[l] = cofs;
+        g.cand_cap[l] = (size_t)g.pyr.w[l] * g.pyr.h[l] / 4 + 64;            // strict 3x3 maxima: at most one per 2x2
+        cofs += g.cand_cap[l];
+    }
+    g.pyr.total = ofs; g.cand_total = cofs;
+    const float factor = (float)(1.0 / (double)1.2f);
+    float nd = ORB_NFEATURES * (1 - factor) / (1 - (float)std::pow((double)factor, (double)ORB_LEVELS));
+    int sum = 0;
+    for (int l = 0; l < ORB_LEVELS - 1; l++) { g.nfeatures[l] = cv_round_f(nd); sum += g.nfeatures[l]; nd *= factor; }
+    g.nfeatures[ORB_LEVELS - 1] = std::max(ORB_NFEATURES - sum, 0);
+    const int half = 15;
+    int um[17] = {0};
+    const int vmax = cv_floor_f(half * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(half * std::sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; v++) um[v] = cv_round_d(std::sqrt((double)half * half - v * v));
+    for (int v = half, v0 = 0; v >= vmin; --v) { while (um[v0] == um[v0 + 1]) ++v0; um[v] = v0; ++v0; }
+    for (int v = 0; v < 16; v++) g.umax.u[v] = um[v];
+    double kd[7], ks = 0;
+    for (int i = 0; i < 7; i++) { const double x = i - 3; kd[i] = std::exp(-0.5 * x * x / 4.0); ks += kd[i]; }
+    for (int i = 0; i < 7; i++) g.g7.k[i] = (float)(kd[i] * (1.0 / ks));
+}
+
+// KeyPointsFilter::retainBest: keep everything with response >= the n-th best
+template <typename T, typename F>
+void retain_best(std::vector<T>& v, int n, F resp) {
+    if (n < 0 || (int)v.size() <= n) return;
+    if (n == 0) { v.clear(); return; }
+    std::vector<float> r(v.size());
+    for (size_t i = 0; i < v.size(); i++) r[i] = resp(v[i]);
+    std::nth_element(r.begin(), r.begin() + (n - 1), r.end(), std::greater<float>());
+    const float thr = r[n - 1];
+    std::vector<T> o;
+    for (auto& k : v) if (resp(k) >= thr) o.push_back(k);
+    v.swap(o);
+}
+
+// ORB on an 8-bit grey image that already sits in level 0 of the workspace pyramid.
+// Descriptors are left on the device in `desc_dev` (n x 32 bytes).
+stk_status orb_run(stk_ctx* ctx, const OrbGeometry& g, uint8_t* desc_dev, size_t desc_cap_rows,
+                   std::vector<HostKeypoint>& out) {
+    KeypointWorkspace* ws = ctx->kp;
+    hipStream_t s = ctx->stream;
+    uint8_t* pyr = ws->pyr.as<uint8_t>();
+    uint8_t* score = ws->score.as<uint8_t>();
+    OrbLevelState* st = ws->states.as<OrbLevelState>();
+    HIP_TRY(hipMemsetAsync(st, 0, sizeof(OrbLevelState) * ORB_LEVELS, s));
+    for (int l = 1; l < ORB_LEVELS; l++)
+        HIP_TRY(launch_resize_exact(pyr + g.pyr.ofs[l - 1], g.pyr.w[l - 1], g.pyr.h[l - 1], pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], s));
+    for (int l = 0; l < ORB_LEVELS; l++) {
+        const int lw = g.pyr.w[l], lh = g.pyr.h[l];
+        if (lw <= 6 || lh <= 6) continue;
+        HIP_TRY(launch_fast_level(pyr + g.pyr.ofs[l], lw, lh, ORB_FAST_THRESHOLD, ORB_EDGE, 2 * g.nfeatures[l], score + g.pyr.ofs[l],
+                                  st + l, ws->cand.as<OrbCandidate>() + g.cand_ofs[l], (int)g.cand_cap[l],
+                                  ws->sel.as<OrbSelected>() + (size_t)l * ORB_SEL_CAP, ORB_SEL_CAP, g.umax, s));
+    }
+    HIP_TRY(hipMemcpyAsync(ws->host_states, st, sizeof(OrbLevelState) * ORB_LEVELS, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int l = 0; l < ORB_LEVELS; l++) {
+        const int n = std::min(ws->host_states[l].n_sel, ORB_SEL_CAP);
+        if (ws->host_states[l].n_sel > ORB_SEL_CAP)
+            return fail(ctx, STK_PROCESSING_ERROR, "ORB: more tied FAST corners than the short list holds");
+        if (n > 0)
+            HIP_TRY(hipMemcpyAsync(ws->host_sel + (size_t)l * ORB_SEL_CAP, ws->sel.as<OrbSelected>() + (size_t)l * ORB_SEL_CAP,
+                                   sizeof(OrbSelected) * n, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+
+    out.clear();
+    std::vector<OrbFinalKeypoint> fin;
+    for (int l = 0; l < ORB_LEVELS; l++) {
+        const int n = std::min(ws->host_states[l].n_sel, ORB_SEL_CAP);
+        std::vector<OrbSelected> v(ws->host_sel + (size_t)l * ORB_SEL_CAP, ws->host_sel + (size_t)l * ORB_SEL_CAP + n);
+        // cull to n_l by the Harris response (ties kept), then a deterministic order
+        retain_best(v, g.nfeatures[l], [](const OrbSelected& k) { return k.harris; });
+        std::sort(v.begin(), v.end(), [](const OrbSelected& p, const OrbSelected& q) {
+            if (p.harris != q.harris) return p.harris > q.harris;
+            const int py = p.xy >> 16, qy = q.xy >> 16;
+            if (py != qy) return py < qy;
+            return (p.xy & 0xffff) < (q.xy & 0xffff);
+        });
+        for (const OrbSelected& k : v) {
+            HostKeypoint hk;
+            hk.lx = k.xy & 0xffff; hk.ly = k.xy >> 16; hk.octave = l;
+            hk.response = k.harris;
+            hk.angle = fast_atan2((float)k.m01, (float)k.m10);
+            hk.size = 31 * g.scale[l];
+            hk.x = (float)hk.lx * g.scale[l]; hk.y = (float)hk.ly * g.scale[l];
+            out.push_back(hk);
+            // computeOrbDescriptors: centre = cvRound(pt * (1/scale)), a = cos(angle deg->rad), b = sin
+            const float inv = 1.f / g.scale[l];
+            float ang = hk.angle;
+            ang *= (float)(3.14159265358979323846 / 180.f);
+            OrbFinalKeypoint f;
+            f.level = l; f.cx = cv_round_f(hk.x * inv); f.cy = cv_round_f(hk.y * inv);
+            f.cos_a = (float)std::cos(ang); f.sin_a = (float)std::sin(ang);
+            fin.push_back(f);
+        }
+    }
+    if (out.size() > desc_cap_rows) { out.resize(desc_cap_rows); fin.resize(desc_cap_rows); }
+    if (fin.empty()) return STK_OK;
+    HIP_TRY(ws->final_kps.reserve(sizeof(OrbFinalKeypoint) * fin.size()));
+    HIP_TRY(hipMemcpyAsync(ws->final_kps.p, fin.data(), sizeof(OrbFinalKeypoint) * fin.size(), hipMemcpyHostToDevice, s));
+    bool have[ORB_LEVELS] = {false};
+    for (const auto& f : fin) have[f.level] = true;
+    for (int l = 0; l < ORB_LEVELS; l++)
+        if (have[l])
+            HIP_TRY(launch_gauss7(pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], g.g7, ws->tmpf.as<float>(), ws->blur.as<uint8_t>() + g.pyr.ofs[l], s));
+    HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)fin.size(), desc_dev, s));
+    HIP_TRY(hipStreamSynchronize(s));     // `fin` is read by the async copy above
+    return STK_OK;
+}
+
+stk_status orb_prepare(stk_ctx* ctx, int w, int h, OrbGeometry& g) {
+    KeypointWorkspace* ws = ctx->kp;
+    orb_geometry(w, h, g);
+    HIP_TRY(ws->pyr.reserve(g.pyr.total));
+    HIP_TRY(ws->score.reserve(g.pyr.total));
+    HIP_TRY(ws->blur.reserve(g.pyr.total));
+    HIP_TRY(ws->tmpf.reserve((size_t)w * h * sizeof(float)));
+    HIP_TRY(ws->cand.reserve(g.cand_total * sizeof(OrbCandidate)));
+    HIP_TRY(ws->sel.reserve(sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS));
+    HIP_TRY(ws->states.reserve(sizeof(OrbLevelState) * ORB_LEVELS));
+    if (!ws->host_sel) HIP_TRY(hipHostMalloc((void**)&ws->host_sel, sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS, hipHostMallocDefault));
+    if (!ws->host_states) HIP_TRY(hipHostMalloc((void**)&ws->host_states, sizeof(OrbLevelState) * ORB_LEVELS, hipHostMallocDefault));
+    if (!ws->pattern_uploaded) { HIP_TRY(upload_orb_pattern(ORB_BIT_PATTERN_31)); ws->pattern_uploaded = true; }
+    return STK_OK;
+}
+
+constexpr size_t MAX_KP = 4096;   // descriptor rows per frame (500 + ties)
+
+struct Match { int q, t; float d; };
+
+}  // namespace
+
+extern "C" {
+
+stk_status stk_orb_detect_and_compute(stk_ctx* ctx, const uint8_t* grey, int32_t width, int32_t height, int32_t location,
+                                      int32_t max_keypoints, float* keypoints, uint8_t* descriptors, int32_t* n_keypoints) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!grey || width <= 0 || height <= 0 || !keypoints || !descriptors || !n_keypoints || max_keypoints <= 0)
+        return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
+    if (width >= 65536 || height >= 32768) return fail(ctx, STK_INVALID_PARAMS, "image too large for ORB");
+    (void)hipSetDevice(ctx->device);
+    OrbGeometry g;
+    stk_status st = orb_prepare(ctx, width, height, g);
+    if (st) return st;
+    KeypointWorkspace* ws = ctx->kp;
+    HIP_TRY(ws->desc.reserve(MAX_KP * 32));
+    HIP_TRY(hipMemcpyAsync(ws->pyr.p, grey, (size_t)width * height,
+                           location == STK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    std::vector<HostKeypoint> kps;
+    if ((st = orb_run(ctx, g, ws->desc.as<uint8_t>(), MAX_KP, kps))) return st;
+    const int n = (int)std::min<size_t>(kps.size(), (size_t)max_keypoints);
+    for (int i = 0; i < n; i++) {
+        float* o = keypoints + (size_t)i * 7;
+        o[0] = kps[i].x; o[1] = kps[i].y; o[2] = kps[i].size; o[3] = kps[i].angle; o[4] = kps[i].response;
+        o[5] = (float)kps[i].octave; o[6] = -1.f;
+    }
+    if (n > 0) HIP_TRY(hipMemcpyAsync(descriptors, ws->desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *n_keypoints = n;
+    return STK_OK;
+}
+
+stk_status stk_bf_knn2_hamming(stk_ctx* ctx, const uint8_t* query, int32_t n_query, const uint8_t* train, int32_t n_train,
+                               int32_t* out) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (n_query < 0 || n_train < 0 || (n_query && (!query || !out)) || (n_train && !train)) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
+    if (n_query == 0) return STK_OK;
+    (void)hipSetDevice(ctx->device);
+    KeypointWorkspace* ws = ctx->kp;
+    HIP_TRY(ws->desc0.reserve((size_t)n_query * 32));
+    HIP_TRY(ws->desc.reserve((size_t)std::max(n_train, 1) * 32));
+    HIP_TRY(ws->knn.reserve((size_t)n_query * 16));
+    HIP_TRY(hipMemcpyAsync(ws->desc0.p, query, (size_t)n_query * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (n_train) HIP_TRY(hipMemcpyAsync(ws->desc.p, train, (size_t)n_train * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_knn2_hamming(ws->desc0.as<uint8_t>(), n_query, ws->desc.as<uint8_t>(), n_train, ws->knn.as<int>(), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, ws->knn.p, (size_t)n_query * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+stk_status stk_find_homography(stk_ctx* ctx, const float* src_pts, const float* dst_pts, int32_t n, int32_t method,
+                               double thr, double* H, uint8_t* inlier_mask, int32_t* found) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!src_pts || !dst_pts || !H || !found) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
+    int f = 0;
+    const int rc = geom::find_homography(src_pts, dst_pts, n, method, thr, H, inlier_mask, &f);
+    *found = f;
+    if (rc == 7) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: LMEDS / RHO are not implemented");
+    if (rc != 0) return fail(ctx, STK_BACKEND_ERROR, "findHomography: needs at least 4 point pairs and a known method");
+    return STK_OK;
+}
+
+stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params,
+                                    float scale_down_width, int32_t add_reference, stk_image_f32* sum,
+                                    int32_t* n_added, int32_t* n_dropped, stk_frame_stats* stats) {
+    stk_status st = check_frames(ctx, frames, true);
+    if (st) return st;
+    if (!params) return fail(ctx, STK_INVALID_PARAMS, "null params");
+    (void)hipSetDevice(ctx->device);
+    if (frames->depth != 8)   // ORB::detectAndCompute asserts an 8-bit image
+        return fail(ctx, STK_BACKEND_ERROR, "ORB: only 8-bit images are supported");
+    if (scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "keypoint_match with scale_down_width (lib.rs:355) is not implemented yet");
+    if (params->method != STK_METHOD_RANSAC && params->method != STK_METHOD_LEAST_SQUARES) {
+        if (params->method == STK_METHOD_LMEDS || params->method == STK_METHOD_RHO)
+            return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: LMEDS / RHO are not implemented");
+        return fail(ctx, STK_BACKEND_ERROR, "findHomography: unknown estimation method");
+    }
+    if (params->border_mode < 0 || params->border_mode > 4)
+        return fail(ctx, params->border_mode == STK_BORDER_TRANSPARENT ? STK_NOT_IMPLEMENTED : STK_BACKEND_ERROR, "unsupported border mode");
+    const int w = frames->width, h = frames->height, n = frames->n;
+    if (w >= 65536 || h >= 32768) return fail(ctx, STK_INVALID_PARAMS, "image too large for ORB");
+    if ((st = image_check(ctx, sum, w, h, 3))) return st;
+    if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
+    timing_begin(ctx);
+
+    std::vector<const void*> dev;
+    if ((st = resolve_frames(ctx, frames, dev))) return st;
+    const size_t rb = frame_row_bytes(frames);
+    OrbGeometry g;
+    if ((st = orb_prepare(ctx, w, h, g))) return st;
+    KeypointWorkspace* ws = ctx->kp;
+    HIP_TRY(ws->desc0.reserve(MAX_KP * 32));
+    HIP_TRY(ws->desc.reserve(MAX_KP * 32));
+    HIP_TRY(ws->knn.reserve(MAX_KP * 16));
+    if (ws->host_knn_cap < MAX_KP * 4) {
+        if (ws->host_knn) (void)hipHostFree(ws->host_knn);
+        HIP_TRY(hipHostMalloc((void**)&ws->host_knn, MAX_KP * 16, hipHostMallocDefault));
+        ws->host_knn_cap = MAX_KP * 4;
+    }
+    if (stats) std::memset(stats, 0, sizeof(stk_frame_stats) * n);
+
+    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    // reference frame: grey -> ORB, descriptors stay in desc0 (lib.rs:161-175)
+    HIP_TRY(launch_grey(dev[0], 8, w, h, rb, ws->pyr.p, ctx->stream));
+    std::vector<HostKeypoint> kp0;
+    if ((st = orb_run(ctx, g, ws->desc0.as<uint8_t>(), MAX_KP, kp0))) return st;
+    const int n0 = (int)kp0.size();
+    if (stats) { stats[0].n_keypoints = n0; stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1; }
+
+    std::vector<WarpFrame> wf;
+    wf.reserve(n);
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (add_reference) { wf.emplace_back(); make_warp_frame(wf.back(), dev[0], I3, 0); }
+    int dropped = 0;
+    std::vector<HostKeypoint> kp;
+    std::vector<Match> ms;
+    for (int i = 1; i < n; i++) {
+        HIP_TRY(launch_grey(dev[i], 8, w, h, rb, ws->pyr.p, ctx->stream));
+        if ((st = orb_run(ctx, g, ws->desc.as<uint8_t>(), MAX_KP, kp))) return st;
+        const int nk = (int)kp.size();
+        bool ok = true;
+        double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        int n_inl = 0;
+        ms.clear();
+        if (n0 > 0) {
+            // knn_match(query = frame-0 descriptors, train = frame-i descriptors, k = 2)  lib.rs:208-219
+            HIP_TRY(launch_knn2_hamming(ws->desc0.as<uint8_t>(), n0, ws->desc.as<uint8_t>(), nk, ws->knn.as<int>(), ctx->stream));
+            HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n0 * 16, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const int* knn = ws->host_knn;
+            for (int q = 0; q < n0; q++) {
+                if (knn[q * 4] < 0 || knn[q * 4 + 2] < 0) continue;                 // m.len() == 2
+                const float d0 = (float)knn[q * 4 + 1], d1 = (float)knn[q * 4 + 3];
+                if (d0 < params->match_ratio * d1) ms.push_back({q, knn[q * 4], d0});   // Lowe ratio lib.rs:224
+            }
+            std::stable_sort(ms.begin(), ms.end(), [](const Match& a, const Match& b) { return a.d < b.d; });   // lib.rs:233
+            const size_t keep = (size_t)std::round((float)ms.size() * params->match_keep_ratio);              // lib.rs:235
+            if (keep < ms.size()) ms.resize(keep);
+        }
+        if (ms.size() < 5) ok = false;                                               // lib.rs:240
+        else {
+            std::vector<float> sp(ms.size() * 2), dp(ms.size() * 2);
+            std::vector<uint8_t> mask(ms.size());
+            for (size_t k = 0; k < ms.size(); k++) {
+                sp[2 * k] = kp0[ms[k].q].x; sp[2 * k + 1] = kp0[ms[k].q].y;          // src_pts: frame 0  lib.rs:245-253
+                dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;            // dst_pts: frame i  lib.rs:256-264
+            }
+            int found = 0;
+            const int rc = geom::find_homography(dp.data(), sp.data(), (int)ms.size(), params->method,
+                                                 params->ransac_reproj_threshold, H, mask.data(), &found);   // lib.rs:267
+            if (rc != 0 || !found) ok = false;                                       // Err(_) | empty -> skip  lib.rs:275-282
+            else {
+                const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
+                if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284
+                for (uint8_t m : mask) n_inl += m;
+            }
+        }
+        if (stats) {
+            stats[i].status = ok ? 0 : 1; stats[i].n_keypoints = nk; stats[i].n_matches = (int)ms.size(); stats[i].n_inliers = n_inl;
+            for (int k = 0; k < 9; k++) stats[i].warp[k] = H[k];
+        }
+        if (!ok) { dropped++; continue; }
+        wf.emplace_back();
+        make_warp_frame(wf.back(), dev[i], H, 0);
+    }
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (wf.empty()) HIP_TRY(hipMemsetAsync(sum->data, 0, image_stride_floats(sum) * h * sizeof(float), ctx->stream));
+    if ((st = warp_fold(ctx, wf, 8, w, h, 3, rb, 1.0 / 255.0, params->border_mode, params->border_value, 0, sum->data,
+                        image_stride_floats(sum), 0))) return st;
+    HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->timing.align_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    ctx->timing.warp_ms = ev_ms(ctx->ev[2], ctx->ev[3]);
+    if (n_added) *n_added = (int32_t)wf.size();
+    if (n_dropped) *n_dropped = dropped;
+    return STK_OK;
+}
+
+stk_status stk_keypoint_match(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params,
+                              float scale_down_width, stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats) {
+    stk_status st = check_frames(ctx, frames, true);
+    if (st) return st;
+    if ((st = image_check(ctx, out, frames->width, frames->height, 3))) return st;
+    if (out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "output must be tightly packed");
+    (void)hipSetDevice(ctx->device);
+    const size_t nel = (size_t)frames->width * frames->height * 3;
+    stk_image_f32 sum = *out;
+    if (out->location != STK_DEVICE) {
+        HIP_TRY(ctx->acc.reserve(nel * sizeof(float)));
+        sum.data = ctx->acc.as<float>(); sum.location = STK_DEVICE;
+    }
+    int32_t added = 0, ndrop = 0;
+    if ((st = stk_keypoint_match_shard(ctx, frames, params, scale_down_width, 1, &sum, &added, &ndrop, stats))) return st;
+    if (dropped) *dropped = ndrop;
+    if (added <= 0)   // lib.rs:324
+        return fail(ctx, STK_INVALID_PARAMS, "All images discarded: try modifying KeyPointMatchParameters::match_distance_threshold");
+    const stk_timing keep = ctx->timing;
+    st = stk_finalize_mean(ctx, &sum, frames->n - ndrop, out);   // lib.rs:342: img / (n - dropped)
+    const double fin = ctx->timing.finalize_ms;
+    ctx->timing = keep; ctx->timing.finalize_ms = fin;
+    return st;
+}
+
+}  // extern "C"

@@ -3,7 +3,33 @@
 #include "common.h"
 
 namespace stk {
+
+constexpr int ORB_LEVELS = 8;
+constexpr int ORB_NFEATURES = 500;
+constexpr int ORB_EDGE = 31;
+constexpr int ORB_FAST_THRESHOLD = 20;
+constexpr int ORB_SEL_CAP = 4096;        // short-list entries per level (2 n_l + ties)
+
+struct OrbCandidate { int xy; int score; };                               // x | y << 16
+struct OrbSelected { int xy; int score; float harris; int m01, m10; int pad; };
+struct OrbLevelState { int hist[256]; int n_cand; int threshold; int n_sel; int pad; };
+struct OrbUmax { int u[16]; };
+struct Gauss7 { float k[7]; };
+struct OrbPyramid { int w[ORB_LEVELS], h[ORB_LEVELS]; size_t ofs[ORB_LEVELS]; size_t total; };
+struct OrbFinalKeypoint { int level, cx, cy; float cos_a, sin_a; };
+
 struct KeypointWorkspace;
 KeypointWorkspace* keypoint_workspace_create();
 void keypoint_workspace_destroy(KeypointWorkspace*);
+
+hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s);
+hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
+                             OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,
+                             const OrbUmax& um, hipStream_t s);
+hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s);
+hipError_t upload_orb_pattern(const signed char* p);
+hipError_t launch_brief(const uint8_t* pyr_blur, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, uint8_t* desc,
+                        hipStream_t s);
+hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s);
+
 }  // namespace stk

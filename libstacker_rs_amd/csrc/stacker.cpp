@@ -9,58 +9,11 @@
 #include <cstring>
 #include <mutex>
 
-#include "common.h"
-#include "keypoint.h"
+#include "context.h"
 
 using namespace stk;
 
-// ---------------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + (bytes >> 3);
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T* as() const { return (T*)p; }
-};
-
-struct stk_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    std::string err;
-    int opt_ecc_slots = 0;        // 0 = auto
-    int opt_subpixel_bits = 0;
-    int opt_profile = 1;
-    int opt_ecc_chunk = 4;
-    int opt_ecc_blocks = 1024;    // total workgroups of one ECC iteration launch (all slots)
-    stk_timing timing{};
-    hipEvent_t ev[8] = {};
-    hipEvent_t poll_ev[2] = {};
-    int* host_done = nullptr;     // pinned, 2 ints
-    std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
-    // workspace
-    DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
-    KeypointWorkspace* kp = nullptr;
-};
-
-static stk_status fail(stk_ctx* ctx, stk_status st, const std::string& msg) {
-    if (ctx) ctx->err = msg;
-    return st;
-}
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(ctx, STK_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(e_));    \
-    } while (0)
-
-static size_t frame_row_bytes(const stk_frames* f) {
+size_t frame_row_bytes(const stk_frames* f) {
     return f->row_stride_bytes ? f->row_stride_bytes : (size_t)f->width * f->channels * (f->depth / 8);
 }
 
@@ -84,7 +37,7 @@ static void invert_affine(const double* m, double* o) {
 }
 
 // Bring the frames of a stack into HBM (no copy when they already are).
-static stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<const void*>& dev) {
+stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<const void*>& dev) {
     const size_t rb = frame_row_bytes(f), fb = rb * f->height;
     dev.resize(f->n);
     if (f->location == STK_DEVICE) { for (int i = 0; i < f->n; i++) dev[i] = f->data[i]; return STK_OK; }
@@ -97,7 +50,7 @@ static stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<
     return STK_OK;
 }
 
-static stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr) {
+stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr) {
     if (!ctx) return STK_INVALID_PARAMS;
     if (!f || f->n <= 0 || !f->data) return fail(ctx, STK_NOT_ENOUGH_FILES, "Not enough files");
     if (f->width <= 0 || f->height <= 0) return fail(ctx, STK_INVALID_PARAMS, "bad frame geometry");
@@ -176,7 +129,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
 
 }  // extern "C"
 
-static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 // ---------------------------------------------------------------------------------------------
 // ECC machinery shared by stk_ecc_match_shard and stk_find_transform_ecc
@@ -325,7 +278,7 @@ static const char* ecc_status_message(int st) {
 }
 
 // fold frames into `sum` (device, tightly packed or strided) through their warps
-static stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
+stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
                             size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
                             int is_affine, float* acc, size_t acc_stride_floats, int accumulate) {
     if (wf.empty()) return STK_OK;
@@ -349,24 +302,24 @@ static stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int 
     return STK_OK;
 }
 
-static void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine) {
+void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine) {
     double inv[9];
     if (is_affine) invert_affine(M, inv); else invert3x3(M, inv);
     wf.src = src;
     for (int k = 0; k < 9; k++) { wf.Md[k] = inv[k]; wf.M[k] = (float)inv[k]; }
 }
 
-static stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c) {
+stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c) {
     if (!im || !im->data) return fail(ctx, STK_INVALID_PARAMS, "null output image");
     if (im->width != w || im->height != h || im->channels != c) return fail(ctx, STK_INVALID_PARAMS, "output image geometry mismatch");
     if (im->row_stride_bytes && im->row_stride_bytes % 4) return fail(ctx, STK_INVALID_PARAMS, "output stride must be a multiple of 4");
     return STK_OK;
 }
-static size_t image_stride_floats(const stk_image_f32* im) {
+size_t image_stride_floats(const stk_image_f32* im) {
     return im->row_stride_bytes ? im->row_stride_bytes / 4 : (size_t)im->width * im->channels;
 }
 
-static void timing_begin(stk_ctx* ctx) { std::memset(&ctx->timing, 0, sizeof(ctx->timing)); }
+void timing_begin(stk_ctx* ctx) { std::memset(&ctx->timing, 0, sizeof(ctx->timing)); }
 
 extern "C" {
 

@@ -143,3 +143,93 @@ def ecc_match(frames, motion=MOTION_HOMOGRAPHY, max_count=5000, epsilon=1e-5, ga
     if rc:
         raise RuntimeError("orc_ecc_match rc=%d" % rc)
     return out, warps, iters
+
+
+# ---- keypoint path -------------------------------------------------------------------------------
+def orb_level_sizes(w: int, h: int, nlevels: int = 8):
+    ws = (C.c_int * nlevels)()
+    hs = (C.c_int * nlevels)()
+    sc = (C.c_float * nlevels)()
+    lib().orc_orb_level_sizes(w, h, nlevels, ws, hs, sc)
+    return list(ws), list(hs), list(sc)
+
+
+def resize_linear_exact(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    s = np.ascontiguousarray(src, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear_exact(_p(s), s.shape[1], s.shape[0], _p(out), dw, dh)
+    return out
+
+
+def fast_score_map(img: np.ndarray, threshold: int = 20) -> np.ndarray:
+    s = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(s)
+    lib().orc_fast_score_map(_p(s), s.shape[1], s.shape[0], int(threshold), _p(out))
+    return out
+
+
+def gauss7_u8(img: np.ndarray) -> np.ndarray:
+    s = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(s)
+    lib().orc_gauss7_u8(_p(s), s.shape[1], s.shape[0], _p(out))
+    return out
+
+
+def orb_detect_and_compute(grey_img: np.ndarray, max_keypoints: int = 4096):
+    """ORB::create_def().detect_and_compute (utils.rs:174-183): (keypoints [n,7] f32, descriptors [n,32] u8)."""
+    g = np.ascontiguousarray(grey_img, np.uint8)
+    kps = np.zeros((max_keypoints, 7), np.float32)
+    des = np.zeros((max_keypoints, 32), np.uint8)
+    n = C.c_int(0)
+    lib().orc_orb_detect_and_compute(_p(g), g.shape[1], g.shape[0], max_keypoints, _p(kps), _p(des), C.byref(n))
+    return kps[: n.value].copy(), des[: n.value].copy()
+
+
+def bf_knn2_hamming(query: np.ndarray, train: np.ndarray) -> np.ndarray:
+    q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+    out = np.full((q.shape[0], 4), -1, np.int32)
+    lib().orc_bf_knn2_hamming(_p(q), q.shape[0], _p(t), t.shape[0], _p(out))
+    return out
+
+
+def rng_sequence(n: int, state: int = 0xFFFFFFFFFFFFFFFF):
+    st = C.c_uint64(state)
+    f = lib().orc_rng_next
+    f.restype = C.c_uint
+    return [f(C.byref(st)) for _ in range(n)]
+
+
+def find_homography(src_pts, dst_pts, method: int = 8, ransac_reproj_threshold: float = 3.0):
+    """calib3d::find_homography(src, dst, method, thr) -> (H 3x3 f64 or None, inlier mask). Raises on bad input."""
+    s = np.ascontiguousarray(src_pts, np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(dst_pts, np.float32).reshape(-1, 2)
+    H = np.zeros(9, np.float64)
+    mask = np.zeros(max(s.shape[0], 1), np.uint8)
+    found = C.c_int(0)
+    rc = lib().orc_find_homography(_p(s), _p(d), s.shape[0], int(method), C.c_double(ransac_reproj_threshold), _p(H),
+                                   _p(mask), C.byref(found))
+    if rc:
+        raise ValueError("orc_find_homography rc=%d" % rc)
+    return (H.reshape(3, 3) if found.value else None), mask[: s.shape[0]]
+
+
+def keypoint_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0, match_keep_ratio: float = 0.80,
+                   match_ratio: float = 0.9, border_mode: int = BORDER_CONSTANT, border_value=(0, 0, 0, 0),
+                   n_threads: int = 0, details: bool = False):
+    """keypoint_match_no_scale (lib.rs:146-353) with the documented drop semantics -> (dropped, image)."""
+    frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+    n = len(frames)
+    h, w, _ = frames[0].shape
+    ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    out = np.empty((h, w, 3), np.float32)
+    bv = np.asarray((list(border_value) + [0] * 4)[:4], np.float64)
+    Hs = np.zeros((n, 3, 3), np.float64)
+    status = np.zeros(n, np.int32)
+    dropped = C.c_int(0)
+    rc = lib().orc_keypoint_match(ptrs, n, w, h, int(method), C.c_double(ransac_reproj_threshold),
+                                  C.c_float(match_keep_ratio), C.c_float(match_ratio), int(border_mode), _p(bv),
+                                  _p(out), C.byref(dropped), _p(Hs), _p(status), int(n_threads))
+    if rc:
+        raise RuntimeError("orc_keypoint_match rc=%d" % rc)
+    return (dropped.value, out, Hs, status) if details else (dropped.value, out)

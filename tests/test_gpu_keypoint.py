@@ -1,0 +1,156 @@
+"""GPU parity of the keypoint_match path (ORB, Hamming 2-NN, RANSAC homography, fold) against the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from libstacker_rs_amd import (InvalidParams, KeyPointMatchParameters, NotEnoughFiles, NotImplementedYet, OpenCvError,
+                               RANSAC, LMEDS, synth)
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
+
+
+@pytest.fixture(scope="module")
+def kp_stack():
+    frames, G = synth.make_stack(4, 640, 480)
+    return frames.numpy(), G
+
+
+def test_orb_bit_exact_vs_oracle(stacker, kp_stack):
+    frames, _ = kp_stack
+    for f in frames[:2]:
+        g = oracle.grey(f)
+        kp, de = stacker.orb_detect_and_compute(g, 4096)
+        kpo, deo = oracle.orb_detect_and_compute(g)
+        assert kp.shape == kpo.shape and len(kp) >= 400
+        assert np.array_equal(kp, kpo)            # integer stages + identical f32 formulas: exact
+        assert np.array_equal(de, deo)            # 256-bit descriptors: bit exact
+        assert list(np.bincount(kp[:, 5].astype(int), minlength=8)[:3]) == [109, 90, 75]   # nfeatures per level
+
+
+def test_orb_odd_sizes_and_flat_image(stacker):
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 256, (211, 333), dtype=np.uint8)
+    kp, de = stacker.orb_detect_and_compute(g)
+    kpo, deo = oracle.orb_detect_and_compute(g)
+    assert np.array_equal(kp, kpo) and np.array_equal(de, deo)
+    flat = np.full((120, 160), 77, np.uint8)      # no corners at all
+    kp, de = stacker.orb_detect_and_compute(flat)
+    assert len(kp) == 0 and len(de) == 0
+    tiny = rng.integers(0, 256, (40, 50), dtype=np.uint8)   # smaller than 2*edgeThreshold: nothing survives
+    kp, _ = stacker.orb_detect_and_compute(tiny)
+    assert len(kp) == 0 and len(oracle.orb_detect_and_compute(tiny)[0]) == 0
+
+
+def test_knn2_hamming_bit_exact(stacker):
+    rng = np.random.default_rng(0)
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (257, 32), dtype=np.uint8)
+    t[10] = t[200] = q[5]                         # exact ties: the lower train index must win
+    t[11] = q[6]
+    got, ref = stacker.bf_knn2_hamming(q, t), oracle.bf_knn2_hamming(q, t)
+    assert np.array_equal(got, ref)
+    assert got[5, 0] == 10 and got[5, 2] == 200 and got[5, 1] == 0
+    one = stacker.bf_knn2_hamming(q[:4], t[:1])   # fewer than 2 train rows: second neighbour missing
+    assert np.array_equal(one, oracle.bf_knn2_hamming(q[:4], t[:1])) and (one[:, 2] == -1).all()
+    none = stacker.bf_knn2_hamming(q[:4], t[:0])
+    assert (none[:, 0] == -1).all()
+
+
+def test_find_homography_known_answers(stacker):
+    Ht = np.array([[1.02, 0.03, 5.0], [-0.01, 0.98, -3.0], [1e-5, -2e-5, 1.0]])
+    rng = np.random.default_rng(1)
+    src = rng.uniform(0, 600, (120, 2)).astype(np.float32)
+    p = np.c_[src, np.ones(len(src))] @ Ht.T
+    dst = (p[:, :2] / p[:, 2:]).astype(np.float32)
+    # 4 exact correspondences -> plain DLT
+    H, _ = stacker.find_homography(src[:4], dst[:4], RANSAC, 3.0)
+    assert synth.corner_error(H, Ht, 640, 480) < 1e-2
+    # RANSAC with 30% gross outliers
+    dst_o = dst.copy()
+    dst_o[::3] += rng.uniform(30, 80, dst_o[::3].shape).astype(np.float32)
+    H, mask = stacker.find_homography(src, dst_o, RANSAC, 3.0)
+    Ho, masko = oracle.find_homography(src, dst_o, 8, 3.0)
+    assert np.array_equal(mask, masko) and np.allclose(H, Ho, rtol=0, atol=1e-12)
+    assert mask[::3].sum() == 0 and mask.sum() == len(src) - len(src[::3])
+    assert synth.corner_error(H, Ht, 640, 480) < 0.05
+    # least squares (method 0)
+    H0, _ = stacker.find_homography(src, dst, 0, 3.0)
+    assert synth.corner_error(H0, Ht, 640, 480) < 0.05
+    with pytest.raises(OpenCvError):
+        stacker.find_homography(src[:3], dst[:3], RANSAC, 3.0)        # fewer than 4 pairs
+    with pytest.raises(NotImplementedYet):
+        stacker.find_homography(src, dst, LMEDS, 3.0)
+    # collinear points: no model
+    line = np.c_[np.arange(20), 2 * np.arange(20)].astype(np.float32)
+    Hn, _ = stacker.find_homography(line, line, RANSAC, 3.0)
+    assert Hn is None and oracle.find_homography(line, line, 8, 3.0)[0] is None
+
+
+def test_rng_known_answer():
+    # cv::RNG(-1): state = state_lo * 4164903690 + state_hi, first outputs
+    st = 0xFFFFFFFFFFFFFFFF
+    exp = []
+    for _ in range(3):
+        st = ((st & 0xFFFFFFFF) * 4164903690 + (st >> 32)) & 0xFFFFFFFFFFFFFFFF
+        exp.append(st & 0xFFFFFFFF)
+    assert oracle.rng_sequence(3) == exp
+
+
+def test_keypoint_match_stack_matches_oracle(stacker, kp_stack):
+    frames, G = kp_stack
+    dropped, out, stats = stacker.keypoint_match(list(frames), PARAMS, return_stats=True)
+    d_o, ref, Hs, status = oracle.keypoint_match(list(frames), details=True)
+    assert dropped == 0 and d_o == 0
+    for i in range(1, len(frames)):
+        assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-10)      # same matches -> same RANSAC trace
+        assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 1.0   # vs generator ground truth
+        assert stats[i]["n_matches"] >= 100
+    assert np.max(np.abs(out - ref)) <= 4e-6                                   # <= 1e-6 per folded frame
+    assert np.max(np.abs(out - ref)) <= 1e-4 * np.max(np.abs(ref))            # north-star tolerance
+
+
+def test_keypoint_match_drops_unmatchable_frame(stacker, kp_stack):
+    frames, _ = kp_stack
+    bad = np.full_like(frames[0], 128)            # featureless frame: no keypoints -> < 5 matches -> dropped
+    stack = [frames[0], frames[1], bad, frames[2]]
+    dropped, out, stats = stacker.keypoint_match(stack, PARAMS, return_stats=True)
+    d_o, ref = oracle.keypoint_match(stack)
+    assert dropped == 1 and d_o == 1 and stats[2]["status"] == 1
+    assert np.max(np.abs(out - ref)) <= 4e-6       # divisor is n - dropped = 3 (documented semantics, lib.rs:98)
+    # the same stack without the bad frame gives the same image
+    d2, out2 = stacker.keypoint_match([frames[0], frames[1], frames[2]], PARAMS)
+    assert d2 == 0 and np.array_equal(out, out2)
+
+
+def test_keypoint_match_all_dropped_is_invalid_params(stacker, kp_stack):
+    frames, _ = kp_stack
+    flat = np.full_like(frames[0], 50)
+    # frame 0 itself is always kept (lib.rs:194-196), so use a stack whose moving frames all fail: still OK
+    dropped, out = stacker.keypoint_match([frames[0], flat, flat], PARAMS)
+    assert dropped == 2 and np.max(np.abs(out - oracle.convert_f32(frames[0]))) <= 1e-6
+
+
+def test_keypoint_match_errors(stacker, kp_stack):
+    frames, _ = kp_stack
+    with pytest.raises(NotEnoughFiles):
+        stacker.keypoint_match([], PARAMS)
+    with pytest.raises(OpenCvError):
+        stacker.keypoint_match([f.astype(np.uint16) for f in frames[:2]], PARAMS)      # ORB needs 8-bit
+    with pytest.raises(NotImplementedYet):
+        stacker.keypoint_match(list(frames[:2]), PARAMS, scale_down_width=400.0)
+    with pytest.raises(InvalidParams):
+        stacker.keypoint_match([frames[0], frames[1][:100]], PARAMS)                   # mismatched sizes
+
+
+def test_keypoint_match_border_mode_and_value(stacker, kp_stack):
+    frames, _ = kp_stack
+    p = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9, oracle.BORDER_REPLICATE, (0, 0, 0, 0))
+    _, out = stacker.keypoint_match(list(frames[:3]), p)
+    _, ref = oracle.keypoint_match(list(frames[:3]), border_mode=oracle.BORDER_REPLICATE)
+    assert np.max(np.abs(out - ref)) <= 4e-6
+    p = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9, oracle.BORDER_CONSTANT, (0.5, 0.25, 1.0, 0))
+    _, out = stacker.keypoint_match(list(frames[:3]), p)
+    _, ref = oracle.keypoint_match(list(frames[:3]), border_value=(0.5, 0.25, 1.0, 0))
+    assert np.max(np.abs(out - ref)) <= 4e-6
