@@ -71,16 +71,14 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     from libstacker_rs_amd import (EccMatchParameters, KeyPointMatchParameters, MotionType, RANSAC, Stacker, synth)
+    from libstacker_rs_amd.shard import shard_moving_frames
 
     W, H, fpg, api = WORKLOADS[args.workload]
     if args.frames_per_gpu > 0:
         fpg = args.frames_per_gpu
     n_global = fpg * world                       # frames in the whole stack (frame 0 = reference)
     # contiguous shards of the moving frames 1..n-1; rank 0 also folds frame 0 itself in
-    moving = list(range(1, n_global))
-    per = [len(moving) // world + (1 if r < len(moving) % world else 0) for r in range(world)]
-    lo = sum(per[:rank])
-    mine = moving[lo:lo + per[rank]]
+    mine = shard_moving_frames(n_global, world, rank)
 
     t0 = time.time()
     scene = synth.render_scene(W, H)

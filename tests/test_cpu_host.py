@@ -1,0 +1,116 @@
+"""CPU tests of the host side: C-ABI exports, parameter/error mirrors, sharding, loud failure without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import libstacker_rs_amd as ls
+from libstacker_rs_amd import _ffi, shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "stacker.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(stk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _ffi.load()                                   # raises if the .so is missing or a symbol is not exported
+    syms = _header_symbols()
+    assert len(syms) >= 19
+    assert sorted(_ffi.SIGNATURES) == syms               # ctypes table == header
+    nm = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (stk_[a-z0-9_]+)", nm))
+    assert set(syms) <= exported
+    assert lib.stk_version().startswith(b"libstacker_rs_amd")
+
+
+def test_library_is_gfx950_only_and_has_no_cpu_fallback():
+    out = subprocess.run(["strings", "-n", "6", _ffi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    src = "".join(open(os.path.join(ROOT, "libstacker_rs_amd", f)).read() for f in ("api.py", "_ffi.py", "__init__.py", "shard.py"))
+    assert "import oracle" not in src and "from oracle" not in src      # the product never touches the oracle
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_ffi.KeypointParams) == 4 + 4 + 8 + 4 + 4 + 4 + 4 + 32      # natural C layout of stk_keypoint_params
+    assert C.sizeof(_ffi.EccParams) == 32
+    assert C.sizeof(_ffi.FrameStats) == 8 + 8 + 16 + 72
+    assert C.sizeof(_ffi.Frames) == 8 + 6 * 4 + 8
+    assert C.sizeof(_ffi.Timing) == 10 * 8
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ls.HipError):
+        ls.Stacker(0)
+    lib = _ffi.load()
+    h = C.c_void_p()
+    assert lib.stk_create(0, C.byref(h)) == 6 and not h.value        # STK_HIP_ERROR, no context
+    assert lib.stk_last_error(None) == b"null context"
+
+
+def test_term_criteria_mapping_doctest():
+    # utils.rs:148-158: max_count None, epsilon 0.1 -> typ == EPS, epsilon 0.1
+    typ, mc, eps = ls.EccMatchParameters(ls.MotionType.Euclidean, None, 0.1, 3).term_criteria()
+    assert (typ, eps) == (2, 0.1)
+    assert ls.EccMatchParameters(ls.MotionType.Homography, 5000, 1e-5, 5).term_criteria() == (3, 5000, 1e-5)
+    assert ls.EccMatchParameters(ls.MotionType.Affine, 10, None, 5).term_criteria()[0] == 1
+    p = ls.EccMatchParameters(ls.MotionType.Homography, None, None, 5)._c()
+    assert (p.has_max_count, p.has_epsilon, p.motion_type) == (0, 0, 3)
+
+
+def test_parameter_defaults_and_constants():
+    d = ls.KeyPointMatchParameters()                     # utils.rs:250-261
+    assert (d.method, d.ransac_reproj_threshold, d.match_keep_ratio, d.match_ratio, d.border_mode) == (8, 3.0, 0.75, 0.8, 0)
+    assert tuple(d.border_value) == (0, 0, 0, 0)
+    c = d._c()
+    assert c.method == 8 and abs(c.match_ratio - 0.8) < 1e-7 and list(c.border_value) == [0, 0, 0, 0]
+    assert [int(m) for m in (ls.MotionType.Translation, ls.MotionType.Euclidean, ls.MotionType.Affine, ls.MotionType.Homography)] == [0, 1, 2, 3]
+    assert (ls.RANSAC, ls.LMEDS, ls.RHO) == (8, 4, 16)
+    for exc in (ls.NotEnoughFiles, ls.InvalidParams, ls.ProcessingError, ls.OpenCvError, ls.IoError):
+        assert issubclass(exc, ls.StackerError)
+
+
+def test_frame_marshalling_rejects_mixed_stacks():
+    from libstacker_rs_amd.api import _Marshalled
+    a = np.zeros((4, 5, 3), np.uint8)
+    m = _Marshalled([a, a.copy()])
+    assert (m.n, m.w, m.h, m.c, m.depth, m.location) == (2, 5, 4, 3, 8, 0)
+    assert _Marshalled(np.zeros((3, 4, 5, 3), np.uint16)).depth == 16
+    with pytest.raises(ls.InvalidParams):
+        _Marshalled([a, np.zeros((4, 6, 3), np.uint8)])
+    with pytest.raises(ls.InvalidParams):
+        _Marshalled([a.astype(np.float64)])
+
+
+def test_shard_partition_properties():
+    for n in (1, 2, 9, 64, 256, 257):
+        for world in (1, 2, 3, 8):
+            parts = [shard.shard_moving_frames(n, world, r) for r in range(world)]
+            flat = [i for p in parts for i in p]
+            assert flat == list(range(1, n))                                 # contiguous, ordered, complete, disjoint
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert shard.shard_moving_frames(256, 8, 0) == list(range(1, 33)) and len(shard.shard_moving_frames(256, 8, 7)) == 31
+    assert shard.shard_frame_list(list("abcdefg"), 2, 1) == ["a", "e", "f", "g"]
+    with pytest.raises(ValueError):
+        shard.shard_moving_frames(4, 2, 2)
+
+
+def test_synthetic_generator_is_seeded_and_sharded_consistently():
+    from libstacker_rs_amd import synth
+    a, Ga = synth.make_stack(3, 96, 64)
+    b, Gb = synth.make_stack(0, 96, 64, indices=[0, 2])
+    assert np.array_equal(a[0].numpy(), b[0].numpy()) and np.array_equal(a[2].numpy(), b[1].numpy())
+    assert np.array_equal(Ga[2], Gb[1]) and np.array_equal(Ga[0], np.eye(3))
+    assert a.dtype.is_floating_point is False and tuple(a.shape) == (3, 64, 96, 3)
+    assert synth.corner_error(np.eye(3), np.eye(3), 96, 64) == 0
+    u16, _ = synth.make_stack(1, 32, 24, depth=16)
+    assert u16.numpy().dtype == np.uint16

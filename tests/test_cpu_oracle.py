@@ -1,0 +1,215 @@
+"""CPU tests: the oracle against the committed golden vectors and against closed-form known answers.
+
+The oracle is the repo's CPU restatement of the OpenCV algorithms libstacker calls ("parity
+unpinned": no OpenCV and no reference fixtures exist here). These tests pin it to
+(a) tests/golden/golden_v1.npz (drift guard), (b) analytic identities, (c) the synthetic generator's
+ground-truth homographies.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from libstacker_rs_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def crop(a):
+    return a[:48, :64]
+
+
+# ---- golden vectors ---------------------------------------------------------------------------------
+def test_golden_integer_stages_bit_exact(gold):
+    f0 = gold["frames"][0]
+    assert np.array_equal(oracle.grey(f0), gold["grey"])
+    assert np.array_equal(oracle.grey(f0.astype(np.uint16) * 257), gold["grey16"])
+    assert np.array_equal(oracle.convert_f32(f0[:16, :16]), gold["convert"])
+    for k in (3, 5, 7):
+        assert np.array_equal(crop(oracle.gaussian_blur_f32(gold["grey"], k)), gold[f"blur{k}"])
+    np.testing.assert_allclose(crop(oracle.gaussian_blur_f32(gold["grey"], 9)), gold["blur9"], rtol=1e-6)
+    gx, gy = oracle.gradients(oracle.gaussian_blur_f32(gold["grey"], 5))
+    assert np.array_equal(crop(gx), gold["grad_x"]) and np.array_equal(crop(gy), gold["grad_y"])
+
+
+def test_golden_warps(gold):
+    f0 = gold["frames"][0]
+    M, A = gold["warp_M"], gold["warp_A"]
+    assert np.array_equal(crop(oracle.warp_frame(f0, M)), gold["warp_exact"])
+    assert np.array_equal(crop(oracle.warp_frame(f0, M, subpixel_bits=5)), gold["warp_classic"])
+    assert np.array_equal(crop(oracle.warp_frame(f0, M, border_mode=oracle.BORDER_REFLECT_101)), gold["warp_reflect"])
+    assert np.array_equal(crop(oracle.warp_frame(f0, A, is_affine=True)), gold["warp_affine"])
+    # exact f32 path and the classic 1/32-px path agree to the quantisation error
+    assert np.max(np.abs(gold["warp_exact"] - gold["warp_classic"])) < 0.02
+
+
+def test_golden_ecc(gold):
+    fr = gold["frames"]
+    g0, g1 = oracle.grey(fr[0]), oracle.grey(fr[1])
+    for name, mot in (("homography", 3), ("affine", 2), ("euclidean", 1), ("translation", 0)):
+        rc, W, rho, its = oracle.find_transform_ecc(g1, g0, np.eye(3 if mot == 3 else 2, 3), mot, 5, None, 5)
+        assert rc == 0 and its == 5
+        np.testing.assert_allclose(W, gold[f"ecc_{name}_warp"], rtol=0, atol=1e-6)
+        assert abs(rho - float(gold[f"ecc_{name}_rho"])) < 1e-9
+    img, warps, iters = oracle.ecc_match(list(fr))
+    assert list(iters) == list(gold["ecc_match_iters"])
+    np.testing.assert_allclose(warps, gold["ecc_match_warps"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(crop(img), gold["ecc_match_image"], rtol=0, atol=2e-6)
+    for i in (1, 2):    # and the recovered warps agree with the generator's truth
+        assert synth.corner_error(warps[i], gold["truth_G"][i], 160, 120) < 0.25
+
+
+def test_golden_keypoint_path(gold):
+    fr = gold["frames"]
+    g0, g1 = oracle.grey(fr[0]), oracle.grey(fr[1])
+    kp0, de0 = oracle.orb_detect_and_compute(g0)
+    kp1, de1 = oracle.orb_detect_and_compute(g1)
+    assert np.array_equal(kp0, gold["orb_kp0"]) and np.array_equal(de0, gold["orb_de0"])
+    assert np.array_equal(kp1, gold["orb_kp1"]) and np.array_equal(de1, gold["orb_de1"])
+    assert np.array_equal(oracle.bf_knn2_hamming(de0, de1), gold["knn01"])
+    assert np.array_equal(np.array(oracle.rng_sequence(8), np.uint32), gold["rng_first8"])
+    d, img, Hs, status = oracle.keypoint_match(list(fr), details=True)
+    assert d == int(gold["kp_match_dropped"]) == 0
+    np.testing.assert_allclose(Hs, gold["kp_match_H"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(crop(img), gold["kp_match_image"], rtol=0, atol=2e-6)
+    for i in (1, 2):
+        assert synth.corner_error(Hs[i], gold["truth_G"][i], 160, 120) < 1.0
+
+
+# ---- closed-form known answers -------------------------------------------------------------------------
+def test_grey_formula_known_pixels():
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]]], np.uint8)
+    exp = [(b * 3735 + g * 19235 + r * 9798 + 16384) >> 15 for b, g, r in px[0].astype(int)]
+    assert list(oracle.grey(px)[0]) == exp and exp[0] == 255 and exp[2] == 29 and exp[3] == 150 and exp[4] == 76
+    px16 = px.astype(np.uint16) * 257
+    exp16 = [(b * 1868 + g * 9617 + r * 4899 + 8192) >> 14 for b, g, r in px16[0].astype(int)]
+    assert list(oracle.grey(px16)[0]) == exp16
+    f = np.array([[[0.5, 0.25, 1.0]]], np.float32)
+    assert oracle.grey(f)[0, 0] == np.float32(np.float32(np.float32(0.5) * np.float32(0.114) + np.float32(0.25) * np.float32(0.587)) + np.float32(1.0) * np.float32(0.299))
+
+
+def test_convert_is_multiply_by_f32_reciprocal():
+    a = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    assert np.array_equal(oracle.convert_f32(a), a.astype(np.float32) * np.float32(1.0 / 255.0))
+    assert oracle.convert_f32(np.array([[65535]], np.uint16))[0, 0] == np.float32(65535) * np.float32(1 / 255.0)   # range 0..257 quirk
+
+
+def test_gaussian_fixed_taps_and_constant_image():
+    lib = oracle.lib()
+    import ctypes as C
+    for n, taps in ((1, [1]), (3, [.25, .5, .25]), (5, [.0625, .25, .375, .25, .0625]),
+                    (7, [.03125, .109375, .21875, .28125, .21875, .109375, .03125])):
+        k = (C.c_float * n)()
+        assert lib.orc_gaussian_kernel(n, k) == 0 and list(k) == taps
+    k = (C.c_float * 9)()
+    lib.orc_gaussian_kernel(9, k)
+    assert abs(sum(k) - 1) < 1e-6 and list(k) == list(k)[::-1]            # sigma = 0.3*((9-1)*0.5-1)+0.8 = 1.7
+    assert lib.orc_gaussian_kernel(4, k) != 0
+    const = np.full((9, 11), 200, np.uint8)
+    assert np.array_equal(oracle.gaussian_blur_f32(const, 5), np.full((9, 11), 200, np.float32))
+    gx, gy = oracle.gradients(np.tile(np.arange(8, dtype=np.float32) * 3, (6, 1)))
+    assert np.all(gx[:, 1:-1] == 3) and np.all(gx[:, [0, -1]] == 0) and np.all(gy == 0)   # REFLECT_101: zero at the rim
+
+
+def test_warp_identity_shift_and_singular():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.warp_frame(img, np.eye(3)), oracle.convert_f32(img))
+    M = np.array([[1, 0, 4], [0, 1, 2], [0, 0, 1.0]])
+    ref = np.zeros((20, 30, 3), np.float32)
+    ref[2:, 4:] = oracle.convert_f32(img)[:-2, :-4]
+    assert np.array_equal(oracle.warp_frame(img, M), ref)
+    assert np.array_equal(oracle.warp_frame(img, np.zeros((3, 3)), border_value=(0.5, 0.5, 0.5, 0)),
+                          np.full((20, 30, 3), 0.5, np.float32))
+    half = oracle.warp_frame(img, np.array([[1, 0, 0.5], [0, 1, 0], [0, 0, 1.0]]))      # half-pixel shift = mean of neighbours
+    c = oracle.convert_f32(img)
+    np.testing.assert_allclose(half[:, 1:], 0.5 * (c[:, :-1] + c[:, 1:]), atol=1e-7)
+    acc = np.ones((20, 30, 3), np.float32)
+    assert np.array_equal(oracle.warp_frame(img, np.eye(3), acc=acc), np.float32(1) + c)
+
+
+def test_scale_is_multiply_by_reciprocal():
+    a = np.array([1.0, 2.0, 3.0, 1e-3], np.float32)
+    assert np.array_equal(oracle.scale(a, 3), a * np.float32(1.0 / 3.0))
+
+
+def test_ecc_recovers_known_translation_and_reports_failures():
+    yy, xx = np.mgrid[0:120, 0:160].astype(np.float64)
+
+    def pat(x, y):
+        return 120 + 60 * np.sin(x / 9.0) * np.cos(y / 7.0) + 40 * np.sin((x + 2 * y) / 23.0)
+    ref = np.clip(pat(xx, yy), 0, 255).astype(np.uint8)
+    mov = np.clip(pat(xx + 3.0, yy - 2.0), 0, 255).astype(np.uint8)
+    rc, W, rho, its = oracle.find_transform_ecc(mov, ref, np.eye(2, 3), oracle.MOTION_TRANSLATION, 300, 1e-8, 5)
+    assert rc == 0 and abs(W[0, 2] - 3) < 0.03 and abs(W[1, 2] + 2) < 0.03 and rho > 0.999
+    rc, *_ = oracle.find_transform_ecc(mov, np.full_like(ref, 9), np.eye(3), oracle.MOTION_HOMOGRAPHY, 50, 1e-5, 5)
+    assert rc == 1                                    # zero variance -> NaN rho -> StsNoConv
+    rc, *_ = oracle.find_transform_ecc(mov, ref, np.eye(3), oracle.MOTION_HOMOGRAPHY, None, None, 5)
+    assert rc == 3                                    # criteria without COUNT or EPS
+    rc, W, rho, its = oracle.find_transform_ecc(mov, ref, np.eye(3), oracle.MOTION_HOMOGRAPHY, 7, None, 5)
+    assert rc == 0 and its == 7                        # COUNT only: exactly max_count iterations
+
+
+def test_orb_structure():
+    fr, _ = synth.make_stack(1, 640, 480)
+    g = oracle.grey(fr[0].numpy())
+    kp, de = oracle.orb_detect_and_compute(g)
+    assert list(np.bincount(kp[:, 5].astype(int), minlength=8)) == [109, 90, 75, 63, 52, 44, 36, 31]
+    ws, hs, sc = oracle.orb_level_sizes(640, 480)
+    assert (ws[0], hs[0], ws[1], hs[1]) == (640, 480, 533, 400)
+    assert np.allclose(kp[:, 2], 31 * np.array(sc, np.float32)[kp[:, 5].astype(int)])
+    for l in range(8):                                  # every keypoint is >= 31 px from its level's border
+        m = kp[:, 5] == l
+        x, y = kp[m, 0] / sc[l], kp[m, 1] / sc[l]
+        assert x.min() >= 31 - 1e-3 and x.max() < ws[l] - 31 and y.min() >= 31 - 1e-3 and y.max() < hs[l] - 31
+    assert (kp[:, 3] >= 0).all() and (kp[:, 3] <= 360).all()
+    # FAST score map: a bright isolated dot is not a corner (its ring is uniformly darker -> it IS one), check symmetry
+    img = np.full((32, 32), 50, np.uint8)
+    img[16, 16] = 200
+    s = oracle.fast_score_map(img)
+    assert s[16, 16] == 149 and s.sum() == 149            # centre brighter than all 16 ring pixels by 150 -> score 149
+
+
+def test_resize_linear_exact_properties():
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (48, 60), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear_exact(a, 60, 48), a)                  # same size: identity
+    c = np.full((30, 36), 77, np.uint8)
+    assert np.all(oracle.resize_linear_exact(c, 30, 25) == 77)
+    r = oracle.resize_linear_exact(a, 50, 40)
+    assert r.shape == (40, 50) and int(r.min()) >= int(a.min()) and int(r.max()) <= int(a.max())
+
+
+def test_knn_ties_and_short_train():
+    q = np.zeros((2, 32), np.uint8)
+    t = np.zeros((3, 32), np.uint8)
+    t[0, 0] = 0b111
+    t[2, 0] = 0b1
+    out = oracle.bf_knn2_hamming(q, t)
+    assert list(out[0]) == [1, 0, 2, 1]
+    t[2, 0] = 0
+    assert list(oracle.bf_knn2_hamming(q, t)[0]) == [1, 0, 2, 0]                   # tie: lower index first
+    assert list(oracle.bf_knn2_hamming(q, t[:1])[0]) == [0, 3, -1, -1]
+
+
+def test_find_homography_exact_and_ransac():
+    Ht = np.array([[0.97, -0.05, 12.0], [0.04, 1.03, -7.0], [3e-5, 1e-5, 1.0]])
+    rng = np.random.default_rng(2)
+    src = rng.uniform(0, 500, (80, 2)).astype(np.float32)
+    p = np.c_[src, np.ones(80)] @ Ht.T
+    dst = (p[:, :2] / p[:, 2:]).astype(np.float32)
+    H, mask = oracle.find_homography(src[:4], dst[:4], 8, 3.0)
+    assert synth.corner_error(H, Ht, 500, 500) < 2e-2 and mask.all()
+    bad = dst.copy()
+    bad[:20] += 50
+    H, mask = oracle.find_homography(src, bad, 8, 3.0)
+    assert mask[:20].sum() == 0 and mask[20:].all() and synth.corner_error(H, Ht, 500, 500) < 0.05
+    assert abs(H[2, 2] - 1) < 1e-12
+    with pytest.raises(ValueError):
+        oracle.find_homography(src[:3], dst[:3], 8, 3.0)
