@@ -24,7 +24,10 @@ namespace stk {
 //  * accumulator     f32 W*H*3 running sum (the Rayon fold accumulator, lib.rs:306-316, 807-814).
 // ---------------------------------------------------------------------------------------------
 
-constexpr int REF_PAD = 2;
+// Zero border of the frame-0 planes, on every side. >= 2 makes a bilinear footprint unconditional after
+// clamping to [-2, W] x [-2, H]; 24 (a multiple of 4: rows stay 16-byte aligned) additionally lets the
+// tiled ECC kernel copy whole 72 x 22 footprints of border tiles with unclamped 16-byte LDS-DMA pieces.
+constexpr int REF_PAD = 24;
 
 struct RefPlanes {
     const float* I;   // pointer to pixel (0,0) inside the padded plane
@@ -110,7 +113,9 @@ hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, si
 // blurred plane (stride in_stride) -> padded I/gx/gy planes
 hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy,
                              int ref_stride, hipStream_t s);
-hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, hipStream_t s);
+// variant: 1 = LDS-tiled (64x16 tiles, double-buffered footprint), 0 = direct global gathers
+hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s);
+constexpr int ECC_TILE_W = 64, ECC_TILE_H = 16;
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
                             EccFrameResult* results, hipStream_t s);
 hipError_t launch_ecc_init(EccSlot* slots, int n_slots, EccQueue* queue, int n_frames, EccFrameResult* results,

@@ -1,21 +1,25 @@
-// kernels_ecc.hip — findTransformECC (lib.rs:769-777; algorithm SURVEY.md §8a-E*) as two kernels
-// per iteration, with the whole iteration loop resident on the device:
+// kernels_ecc.hip — the fused iteration pass of findTransformECC (lib.rs:769-777; algorithm
+// SURVEY.md §8a-E*). The solve step and the device-side frame queue are in kernels_ecc_solve.hip.
 //
-//  ecc_iter   ONE fused pass per iteration and slot: per template pixel, projective coordinates ->
-//             bilinear gathers of (I, gx, gy) from the zero-padded frame-0 planes -> nearest mask ->
-//             Jacobian in registers -> 66 moment sums (36 Hessian, 8 J.Iw, 8 J.T.m, 8 J.m, 6 scalars)
-//             accumulated in f32 per lane, reduced with wavefront shuffles, then LDS across the
-//             four waves, written as f64 block partials. OpenCV materialises ~150 f32 planes per
-//             iteration for the same result; here the algorithmic traffic is 16 B/px.
-//  ecc_solve  one block per slot: fixed-order f64 sum of the block partials (deterministic), then
-//             the 8x8 normal equations exactly as OpenCV forms them (f32 Hessian, LU inverse in
-//             f32, lambda in f64), warp update, convergence test, and — when a frame finishes —
-//             hand the slot the next frame from the device-side queue. The host never sees an
-//             iteration; it only polls EccQueue::frames_done.
+//  ONE pass per iteration and slot: per template pixel, projective coordinates -> bilinear taps of
+//  (I, gx, gy) from the zero-padded frame-0 planes -> nearest mask -> Jacobian in registers -> 66
+//  moment sums (36 Hessian, 8 J.Iw, 8 J.T.m, 8 J.m, 6 scalars) accumulated in f32 per lane, reduced
+//  with wavefront shuffles, then across the four waves through LDS in f64, written as f64 block
+//  partials. OpenCV materialises ~150 f32 planes per iteration for the same result; here the
+//  algorithmic traffic is 16 B/px.
 //
-// Several frames ("slots") iterate concurrently in one launch. blockIdx is decoded so that the
-// blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD
-// and its L2: the frame-0 planes they all gather from are fetched from HBM/MALL once per XCD.
+//  Two variants of the pass, same arithmetic per pixel (bit-identical results):
+//   * tiled (default): a workgroup walks 64x16-pixel tiles. The source footprint of a tile (the
+//     bounding box of its four warped corners, + margin) is staged in LDS for all three planes,
+//     double-buffered: the global loads of tile k+1 are issued before tile k is computed and written
+//     to the other LDS buffer afterwards, so HBM/L2 latency hides behind ~1000 px of arithmetic and
+//     every tap is an LDS read. Tiles whose footprint does not fit (large rotations / zooms) fall
+//     back to direct gathers.
+//   * direct: every tap is a global gather (L1/L2 absorb the overlap between neighbouring lanes).
+//
+//  Several frames ("slots") iterate concurrently in one launch. blockIdx is decoded so that the
+//  blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD and
+//  its L2: the frame-0 planes they all read are fetched from HBM/MALL once per XCD.
 #include "common.h"
 
 namespace stk {
@@ -28,12 +32,11 @@ template <> struct MotionTraits<STK_MOTION_EUCLIDEAN> { static constexpr int P =
 template <> struct MotionTraits<STK_MOTION_AFFINE> { static constexpr int P = 6; };
 template <> struct MotionTraits<STK_MOTION_HOMOGRAPHY> { static constexpr int P = 8; };
 
-__device__ __forceinline__ float bilerp(f32x2_a4 top, f32x2_a4 bot, float ax, float ay) {
-    const float v0 = __builtin_fmaf(ax, top.y - top.x, top.x);
-    const float v1 = __builtin_fmaf(ax, bot.y - bot.x, bot.x);
+__device__ __forceinline__ float bilerp4(float p00, float p01, float p10, float p11, float ax, float ay) {
+    const float v0 = __builtin_fmaf(ax, p01 - p00, p00);
+    const float v1 = __builtin_fmaf(ax, p11 - p10, p10);
     return __builtin_fmaf(ay, v1 - v0, v0);
 }
-
 
 __device__ __forceinline__ int sat_round_d(double v) {
     if (!(v > -2147483648.0)) return (int)0x80000000;
@@ -61,130 +64,119 @@ __device__ __noinline__ bool nearest_inside_exact(int x, int y, const float* m, 
     return ((unsigned)mx < (unsigned)iw) & ((unsigned)my < (unsigned)ih);
 }
 
+// Per-launch constants of one slot, kept in scalar registers.
+struct SlotConst {
+    float m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    float cI, cT;
+    bool den_is_w;
+    float fiw, fih, mxw, mxh;
+    int iw, ih;
+};
+
+// warped source coordinate of template pixel (x, y): sx, sy and the Jacobian helpers
 template <int MOTION>
-__global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
+__device__ __forceinline__ void warp_coord(const SlotConst& c, float fx, float fy, float& sx, float& sy, float& rden,
+                                           float& hx, float& hy) {
+    sx = __builtin_fmaf(c.m0, fx, __builtin_fmaf(c.m1, fy, c.m2));
+    sy = __builtin_fmaf(c.m3, fx, __builtin_fmaf(c.m4, fy, c.m5));
+    rden = 1.0f; hx = 0.0f; hy = 0.0f;
+    if constexpr (MOTION == STK_MOTION_HOMOGRAPHY) {
+        // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the result is still deterministic,
+        // and a last-bit difference in 1/w moves the sample point by < 3e-4 px at 4K
+        const float rw = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m6, fx, __builtin_fmaf(c.m7, fy, c.m8)));
+        rden = rw;
+        if (!c.den_is_w) rden = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m6, fx, __builtin_fmaf(c.m7, fy, 1.0f)));   // den = X*h2 + Y*h5 + 1
+        hx = -sx * rden; hy = -sy * rden;                                                          // hatX, hatY
+        sx *= rw; sy *= rw;
+    }
+}
+
+// Everything after the taps: mask, Jacobian, the 66 fused multiply-adds.
+template <int MOTION, int NS>
+__device__ __forceinline__ void accumulate_pixel(const SlotConst& c, const float* warp, int x, int y, float fx, float fy,
+                                                 float sx, float sy, float rden, float hx, float hy, float Iw, float gxw,
+                                                 float gyw, float tval, float (&acc)[NS]) {
     constexpr int P = MotionTraits<MOTION>::P;
     constexpr int NH = P * (P + 1) / 2;
-    constexpr int NS = NH + 3 * P + 6;
-
-    // XCD-aware decode: bid = xcd + 8 * (slot + n_slots * (region / 8))
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = bid >> 3;
-    const int slot = q % a.n_slots;
-    const int region = (q / a.n_slots) * 8 + xcd;
-
-    const EccSlot* sl = a.slots + slot;
-    const int frame = sl->frame;
-    if (frame < 0) return;                                    // idle slot: whole block leaves
-
-    const float m0 = sl->warp[0], m1 = sl->warp[1], m2 = sl->warp[2];
-    const float m3 = sl->warp[3], m4 = sl->warp[4], m5 = sl->warp[5];
-    const float m6 = sl->warp[6], m7 = sl->warp[7], m8 = sl->warp[8];
-    const float cI = sl->cI, cT = sl->cT;
-    const bool den_is_w = (m8 == 1.0f);
-
-    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
-    const float* __restrict__ RI = a.ref.I;
-    const float* __restrict__ RX = a.ref.gx;
-    const float* __restrict__ RY = a.ref.gy;
-    const int rs = a.ref.stride;
-    const float fiw = (float)a.ref.w, fih = (float)a.ref.h;
-    const float mxw = (float)(a.ref.w - 1), mxh = (float)(a.ref.h - 1);
-
-    float acc[NS];
-#pragma unroll
-    for (int k = 0; k < NS; k++) acc[k] = 0.f;
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qw = (a.tw + 3) >> 2;                           // quads per row
-
-    for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
-        const float fy = (float)y;
-        const float rowX = __builtin_fmaf(m1, fy, m2);
-        const float rowY = __builtin_fmaf(m4, fy, m5);
-        const float rowW = __builtin_fmaf(m7, fy, m8);
-        const float rowD = __builtin_fmaf(m7, fy, 1.0f);
-        const float* trow = T + (size_t)y * a.templ_row_stride;
-        for (int qx = lane; qx < qw; qx += 64) {
-            const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
-            const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = qx * 4 + j;
-                if (x < a.tw) {
-                    const float fx = (float)x;
-                    float sx = __builtin_fmaf(m0, fx, rowX);
-                    float sy = __builtin_fmaf(m3, fx, rowY);
-                    float rden = 1.0f, hx = 0.0f, hy = 0.0f;      // 1/den, hatX, hatY of the homography Jacobian
-                    if constexpr (MOTION == STK_MOTION_HOMOGRAPHY) {
-                        const float rw = 1.0f / __builtin_fmaf(m6, fx, rowW);
-                        rden = rw;
-                        if (!den_is_w) rden = 1.0f / __builtin_fmaf(m6, fx, rowD);   // den = X*h2 + Y*h5 + 1
-                        hx = -sx * rden; hy = -sy * rden;
-                        sx *= rw; sy *= rw;
-                    }
-                    const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
-                    const float ax = sx - flx, ay = sy - fly;
-                    // clamp the integer coordinate into the zero border; NaN -> -2 (all taps zero)
-                    const int ix = (int)__builtin_fminf(__builtin_fmaxf(flx, -2.0f), fiw);
-                    const int iy = (int)__builtin_fminf(__builtin_fmaxf(fly, -2.0f), fih);
-                    const int off = iy * rs + ix;
-                    const float Iw = bilerp(*(const f32x2_a4*)(RI + off), *(const f32x2_a4*)(RI + off + rs), ax, ay);
-                    const float gxw = bilerp(*(const f32x2_a4*)(RX + off), *(const f32x2_a4*)(RX + off + rs), ax, ay);
-                    const float gyw = bilerp(*(const f32x2_a4*)(RY + off), *(const f32x2_a4*)(RY + off + rs), ax, ay);
-                    // INTER_NEAREST mask: rounded source coordinate inside the input image. OpenCV rounds
-                    // a double (homography) or 10-bit fixed-point (affine) coordinate; the f32 value decides
-                    // except within 0.01 px of a boundary of the valid range, where the exact form is redone.
-                    const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
-                    bool inside = (rx >= 0.0f) & (rx <= mxw) & (ry >= 0.0f) & (ry <= mxh);
-                    const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (mxw + 0.5f)) < 0.01f) |
-                                      (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (mxh + 0.5f)) < 0.01f);
-                    if (edge) inside = nearest_inside_exact<MOTION>(x, y, sl->warp, a.ref.w, a.ref.h);
-                    const float mf = inside ? 1.0f : 0.0f;
-
-                    float J[P];
-                    if constexpr (MOTION == STK_MOTION_HOMOGRAPHY) {
-                        const float ja = gxw * rden, jb = gyw * rden;
-                        const float jt = hx * ja + hy * jb;
-                        J[0] = ja * fx; J[1] = jb * fx; J[2] = jt * fx;
-                        J[3] = ja * fy; J[4] = jb * fy; J[5] = jt * fy;
-                        J[6] = ja; J[7] = jb;
-                    } else if constexpr (MOTION == STK_MOTION_AFFINE) {
-                        J[0] = gxw * fx; J[1] = gyw * fx; J[2] = gxw * fy; J[3] = gyw * fy; J[4] = gxw; J[5] = gyw;
-                    } else if constexpr (MOTION == STK_MOTION_EUCLIDEAN) {
-                        const float ex = -(fx * m3) - (fy * m0);     // h0 = m00 (cos), h1 = m10 (sin)
-                        const float ey = (fx * m0) - (fy * m3);
-                        J[0] = gxw * ex + gyw * ey; J[1] = gxw; J[2] = gyw;
-                    } else {
-                        J[0] = gxw; J[1] = gyw;
-                    }
-                    // centred samples: u = Iw - cI inside the mask (Iw outside), v = (T - cT) inside, 0 outside
-                    const float u = inside ? Iw - cI : Iw;
-                    const float v = inside ? tv[j] - cT : 0.0f;
-                    int idx = 0;
-#pragma unroll
-                    for (int k = 0; k < P; k++)
-#pragma unroll
-                        for (int l = k; l < P; l++) { acc[idx] = __builtin_fmaf(J[k], J[l], acc[idx]); idx++; }
-#pragma unroll
-                    for (int k = 0; k < P; k++) {
-                        acc[NH + k] = __builtin_fmaf(J[k], u, acc[NH + k]);
-                        acc[NH + P + k] = __builtin_fmaf(J[k], v, acc[NH + P + k]);
-                        acc[NH + 2 * P + k] = __builtin_fmaf(J[k], mf, acc[NH + 2 * P + k]);
-                    }
-                    const float um = u * mf;
-                    acc[NH + 3 * P + 0] += mf;
-                    acc[NH + 3 * P + 1] += um;
-                    acc[NH + 3 * P + 2] = __builtin_fmaf(um, u, acc[NH + 3 * P + 2]);
-                    acc[NH + 3 * P + 3] += v;
-                    acc[NH + 3 * P + 4] = __builtin_fmaf(v, v, acc[NH + 3 * P + 4]);
-                    acc[NH + 3 * P + 5] = __builtin_fmaf(um, v, acc[NH + 3 * P + 5]);
-                }
-            }
-        }
+    // INTER_NEAREST mask: rounded source coordinate inside the input image. OpenCV rounds a double
+    // (homography) or 10-bit fixed-point (affine) coordinate; the f32 value decides except within
+    // 0.01 px of a boundary of the valid range, where the exact form is redone.
+    // Pixels whose source coordinate is strictly inside [0, W-1] x [0, H-1] (all but a thin rim) skip all of that.
+    bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
+    if (!inside) {
+        const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
+        inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
+        const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
+                          (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
+        if (edge) inside = nearest_inside_exact<MOTION>(x, y, warp, c.iw, c.ih);
     }
+    const float mf = inside ? 1.0f : 0.0f;
 
-    // wavefront reduction (64 lanes), then the four waves through LDS in f64
+    float J[P];
+    if constexpr (MOTION == STK_MOTION_HOMOGRAPHY) {
+        const float ja = gxw * rden, jb = gyw * rden;
+        const float jt = hx * ja + hy * jb;
+        J[0] = ja * fx; J[1] = jb * fx; J[2] = jt * fx;
+        J[3] = ja * fy; J[4] = jb * fy; J[5] = jt * fy;
+        J[6] = ja; J[7] = jb;
+    } else if constexpr (MOTION == STK_MOTION_AFFINE) {
+        J[0] = gxw * fx; J[1] = gyw * fx; J[2] = gxw * fy; J[3] = gyw * fy; J[4] = gxw; J[5] = gyw;
+    } else if constexpr (MOTION == STK_MOTION_EUCLIDEAN) {
+        const float ex = -(fx * c.m3) - (fy * c.m0);     // h0 = m00 (cos), h1 = m10 (sin)
+        const float ey = (fx * c.m0) - (fy * c.m3);
+        J[0] = gxw * ex + gyw * ey; J[1] = gxw; J[2] = gyw;
+    } else {
+        J[0] = gxw; J[1] = gyw;
+    }
+    // centred samples: u = Iw - cI inside the mask (Iw outside), v = (T - cT) inside, 0 outside
+    const float u = inside ? Iw - c.cI : Iw;
+    const float v = inside ? tval - c.cT : 0.0f;
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < P; k++)
+#pragma unroll
+        for (int l = k; l < P; l++) { acc[idx] = __builtin_fmaf(J[k], J[l], acc[idx]); idx++; }
+#pragma unroll
+    for (int k = 0; k < P; k++) {
+        acc[NH + k] = __builtin_fmaf(J[k], u, acc[NH + k]);
+        acc[NH + P + k] = __builtin_fmaf(J[k], v, acc[NH + P + k]);
+        acc[NH + 2 * P + k] = __builtin_fmaf(J[k], mf, acc[NH + 2 * P + k]);
+    }
+    const float um = u * mf;
+    acc[NH + 3 * P + 0] += mf;
+    acc[NH + 3 * P + 1] += um;
+    acc[NH + 3 * P + 2] = __builtin_fmaf(um, u, acc[NH + 3 * P + 2]);
+    acc[NH + 3 * P + 3] += v;
+    acc[NH + 3 * P + 4] = __builtin_fmaf(v, v, acc[NH + 3 * P + 4]);
+    acc[NH + 3 * P + 5] = __builtin_fmaf(um, v, acc[NH + 3 * P + 5]);
+}
+
+// direct path: taps gathered from global memory (zero border makes them unconditional)
+template <int MOTION, int NS>
+__device__ __forceinline__ void pixel_direct(const SlotConst& c, const EccIterArgs& a, const float* warp, int x, int y,
+                                             float tval, float (&acc)[NS]) {
+    const float fx = (float)x, fy = (float)y;
+    float sx, sy, rden, hx, hy;
+    warp_coord<MOTION>(c, fx, fy, sx, sy, rden, hx, hy);
+    const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
+    const float ax = sx - flx, ay = sy - fly;
+    // clamp the integer coordinate into the zero border; NaN -> -2 (all taps zero)
+    const int ix = (int)__builtin_fminf(__builtin_fmaxf(flx, -2.0f), c.fiw);
+    const int iy = (int)__builtin_fminf(__builtin_fmaxf(fly, -2.0f), c.fih);
+    const int rs = a.ref.stride;
+    const int off = iy * rs + ix;
+    const f32x2_a4 i0 = *(const f32x2_a4*)(a.ref.I + off), i1 = *(const f32x2_a4*)(a.ref.I + off + rs);
+    const f32x2_a4 x0 = *(const f32x2_a4*)(a.ref.gx + off), x1 = *(const f32x2_a4*)(a.ref.gx + off + rs);
+    const f32x2_a4 y0 = *(const f32x2_a4*)(a.ref.gy + off), y1 = *(const f32x2_a4*)(a.ref.gy + off + rs);
+    const float Iw = bilerp4(i0.x, i0.y, i1.x, i1.y, ax, ay);
+    const float gxw = bilerp4(x0.x, x0.y, x1.x, x1.y, ax, ay);
+    const float gyw = bilerp4(y0.x, y0.y, y1.x, y1.y, ax, ay);
+    accumulate_pixel<MOTION, NS>(c, warp, x, y, fx, fy, sx, sy, rden, hx, hy, Iw, gxw, gyw, tval, acc);
+}
+
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NS], const EccIterArgs& a, int slot, int region) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         float v = acc[k];
@@ -205,8 +197,236 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
     }
 }
 
-hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, hipStream_t s) {
+__device__ __forceinline__ void load_slot_const(const EccSlot* sl, const EccIterArgs& a, SlotConst& c) {
+    c.m0 = sl->warp[0]; c.m1 = sl->warp[1]; c.m2 = sl->warp[2];
+    c.m3 = sl->warp[3]; c.m4 = sl->warp[4]; c.m5 = sl->warp[5];
+    c.m6 = sl->warp[6]; c.m7 = sl->warp[7]; c.m8 = sl->warp[8];
+    c.cI = sl->cI; c.cT = sl->cT;
+    c.den_is_w = (c.m8 == 1.0f);
+    c.iw = a.ref.w; c.ih = a.ref.h;
+    c.fiw = (float)a.ref.w; c.fih = (float)a.ref.h;
+    c.mxw = (float)(a.ref.w - 1); c.mxh = (float)(a.ref.h - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// direct variant: one wave per template row, lanes stream aligned 16-byte template quads
+// ---------------------------------------------------------------------------------------------------
+template <int MOTION>
+__global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
+    constexpr int P = MotionTraits<MOTION>::P;
+    constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
+    // XCD-aware decode: bid = xcd + 8 * (slot + n_slots * (region / 8))
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int slot = q % a.n_slots;
+    const int region = (q / a.n_slots) * 8 + xcd;
+    const EccSlot* sl = a.slots + slot;
+    const int frame = sl->frame;
+    if (frame < 0) return;                                    // idle slot: whole block leaves
+    SlotConst c;
+    load_slot_const(sl, a, c);
+    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
+
+    float acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) acc[k] = 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qw = (a.tw + 3) >> 2;                           // quads per row
+    for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
+        const float* trow = T + (size_t)y * a.templ_row_stride;
+        for (int qx = lane; qx < qw; qx += 64) {
+            const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                const int x = qx * 4 + j;
+                const float tvj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
+                if (x < a.tw) pixel_direct<MOTION, NS>(c, a, sl->warp, x, y, tvj, acc);
+            }
+        }
+    }
+    block_reduce_store<NS>(acc, a, slot, region);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tiled variant: 64 x 16 pixel tiles, source footprint double-buffered in LDS
+// ---------------------------------------------------------------------------------------------------
+constexpr int TILE_W = 64, TILE_H = 16;
+constexpr int REG_W = 72, REG_H = 22;                          // LDS footprint per plane (floats)
+constexpr int REG_N = 3 * REG_W * REG_H;                        // 4752 floats
+constexpr int REG_CHUNKS = REG_N / 4;                           // 16-byte pieces of the footprint (1188)
+constexpr int STAGE_R = (REG_CHUNKS + 255) / 256;               // LDS-DMA instructions per thread for the footprint (5)
+constexpr int REG_PAD_N = STAGE_R * 256 * 4;                    // footprint rounded up to whole wave-instructions (5120 floats)
+constexpr int TBUF_N = TILE_W * TILE_H;                         // template tile, 1024 floats
+constexpr int BUF_FLOATS = REG_PAD_N + TBUF_N;                  // 5888 floats = 23.0 KB per buffer
+
+struct TileInfo { int x0, y0, rx0, ry0; bool fits; };
+
+template <int MOTION>
+__device__ __forceinline__ TileInfo tile_info(const SlotConst& c, int tile, int tiles_x) {
+    TileInfo t;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    t.x0 = tx * TILE_W; t.y0 = ty * TILE_H;
+    // bounding box of the warped tile corners (a projective map with w > 0 keeps the quad convex)
+    // one corner per lane (lane & 3), combined with two butterfly steps: 1 coordinate evaluation instead of 4
+    const int k = threadIdx.x & 3;
+    const float fx = (float)(t.x0 + ((k & 1) ? TILE_W - 1 : 0)), fy = (float)(t.y0 + ((k & 2) ? TILE_H - 1 : 0));
+    float sx, sy, rden, hx, hy;
+    warp_coord<MOTION>(c, fx, fy, sx, sy, rden, hx, hy);
+    bool okl = (__builtin_fabsf(sx) < 1.0e7f) & (__builtin_fabsf(sy) < 1.0e7f);
+    if constexpr (MOTION == STK_MOTION_HOMOGRAPHY) okl &= (rden > 0.0f) & (rden < 1.0e6f);
+    if (!okl) { sx = __builtin_nanf(""); sy = sx; }              // poison: fmin/fmax below would drop a NaN, so track it
+    float bad = okl ? 0.0f : 1.0f;
+    float mnx = sx, mxx = sx, mny = sy, mxy = sy;
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+        mnx = __builtin_fminf(mnx, __shfl_xor(mnx, o, 64)); mxx = __builtin_fmaxf(mxx, __shfl_xor(mxx, o, 64));
+        mny = __builtin_fminf(mny, __shfl_xor(mny, o, 64)); mxy = __builtin_fmaxf(mxy, __shfl_xor(mxy, o, 64));
+        bad = __builtin_fmaxf(bad, __shfl_xor(bad, o, 64));
+    }
+    const bool ok = __builtin_amdgcn_readfirstlane(bad == 0.0f ? 1 : 0) != 0;
+    if (!ok) { t.rx0 = 0; t.ry0 = 0; t.fits = false; return t; }
+    // origin one texel before the box, rounded down to a multiple of 4 columns (16-byte DMA pieces)
+    const int bx0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mnx)), bx1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mxx));
+    const int by0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mny)), by1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mxy));
+    t.rx0 = (bx0 - 1) & ~3; t.ry0 = by0 - 1;
+    // taps reach floor(max)+1; keep one more column/row of slack on the far side. The whole footprint
+    // must lie inside the zero-padded plane, because the pieces are copied without clamping.
+    t.fits = (bx1 + 2 - t.rx0 < REG_W) & (by1 + 2 - t.ry0 < REG_H) &
+             (t.rx0 >= -REF_PAD) & (t.rx0 + REG_W <= c.iw + REF_PAD) & (t.ry0 >= -REF_PAD) & (t.ry0 + REG_H <= c.ih + REF_PAD);
+    return t;
+}
+
+template <int MOTION>
+__global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
+    constexpr int P = MotionTraits<MOTION>::P;
+    constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF_FLOATS
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int slot = q % a.n_slots;
+    const int region = (q / a.n_slots) * 8 + xcd;
+    const EccSlot* sl = a.slots + slot;
+    const int frame = sl->frame;
+    if (frame < 0) return;
+    SlotConst c;
+    load_slot_const(sl, a, c);
+    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
+    const int tid = threadIdx.x;
+    const int tiles_x = (a.tw + TILE_W - 1) / TILE_W, tiles_y = (a.th + TILE_H - 1) / TILE_H;
+    const int n_tiles = tiles_x * tiles_y;
+    const int rs = a.ref.stride;
+    const size_t plane = (size_t)rs * (a.ref.h + 2 * REF_PAD);
+
+    float acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) acc[k] = 0.f;
+
+    // Stage one tile into an LDS buffer with LDS-DMA (global_load_lds_dword): each wave instruction
+    // gathers 64 dwords from per-lane global addresses into 64 consecutive LDS dwords, no VGPRs held,
+    // completion counted on vmcnt and drained by the barrier that precedes the buffer's first read.
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // per-thread piece offsets inside a footprint (tile independent): plane * plane_stride + row * rs + 4 * cx
+    int coff[STAGE_R];
+#pragma unroll
+    for (int j = 0; j < STAGE_R; j++) {
+        const int e = min(tid + 256 * j, REG_CHUNKS - 1);           // 16-byte piece; tail lanes land in the pad
+        const int row = e / (REG_W / 4), cx = e - row * (REG_W / 4); // row over all three planes
+        const int p = row / REG_H, ry = row - p * REG_H;
+        coff[j] = p * (int)plane + ry * rs + 4 * cx;
+    }
+    const int toff_t = (tid >> 4) * a.templ_row_stride + 4 * (tid & 15);
+    auto stage_dma = [&](const TileInfo& t, float* buf) {
+        if (t.fits) {
+            const float* g0 = a.ref.I + ((ptrdiff_t)t.ry0 * rs + t.rx0);
+#pragma unroll
+            for (int j = 0; j < STAGE_R; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + coff[j]),
+                                                 (__attribute__((address_space(3))) void*)(buf + (wave_u * 64 + 256 * j) * 4), 16, 0, 0);
+        }
+        {   // template tile: 16 rows x 16 pieces, one per thread (rows are 16-byte aligned, stride % 4 == 0)
+            const int rowc = min((tid >> 4), a.th - 1 - t.y0);       // rows below the image repeat the last one (unused)
+            const float* g = T + ((size_t)t.y0 * a.templ_row_stride + t.x0) + (rowc == (tid >> 4) ? toff_t : rowc * a.templ_row_stride + 4 * (tid & 15));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(buf + REG_PAD_N + wave_u * 256), 16, 0, 0);
+        }
+    };
+
+    int tile = region;
+    if (tile < n_tiles) {
+        TileInfo cur = tile_info<MOTION>(c, tile, tiles_x);
+        stage_dma(cur, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int b = 0;
+        while (true) {
+            const int next = tile + a.nb;
+            const bool has_next = next < n_tiles;
+            TileInfo nxt = cur;
+            if (has_next) { nxt = tile_info<MOTION>(c, next, tiles_x); stage_dma(nxt, lds + (b ^ 1) * BUF_FLOATS); }
+            const float* buf = lds + b * BUF_FLOATS;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ly = (tid >> 6) + 4 * j, lx = tid & 63;
+                const int x = cur.x0 + lx, y = cur.y0 + ly;
+                if (x < a.tw && y < a.th) {
+                    const float tval = buf[REG_PAD_N + ly * TILE_W + lx];
+                    const float fx = (float)x, fy = (float)y;
+                    float sx, sy, rden, hx, hy;
+                    warp_coord<MOTION>(c, fx, fy, sx, sy, rden, hx, hy);
+                    const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
+                    const float ax = sx - flx, ay = sy - fly;
+                    float i00, i01, i10, i11, x00, x01, x10, x11, y00, y01, y10, y11;
+                    if (cur.fits) {
+                        // inside the staged footprint by construction; the clamp only guards NaNs
+                        const int ix = min(max((int)flx - cur.rx0, 0), REG_W - 2);
+                        const int iy = min(max((int)fly - cur.ry0, 0), REG_H - 2);
+                        const float* p = buf + iy * REG_W + ix;
+                        i00 = p[0]; i01 = p[1]; i10 = p[REG_W]; i11 = p[REG_W + 1];
+                        const float* px = p + REG_W * REG_H;
+                        x00 = px[0]; x01 = px[1]; x10 = px[REG_W]; x11 = px[REG_W + 1];
+                        const float* py = px + REG_W * REG_H;
+                        y00 = py[0]; y01 = py[1]; y10 = py[REG_W]; y11 = py[REG_W + 1];
+                    } else {
+                        // footprint too large for LDS (strong rotation / zoom): gather the taps directly
+                        const int ix = (int)__builtin_fminf(__builtin_fmaxf(flx, -2.0f), c.fiw);
+                        const int iy = (int)__builtin_fminf(__builtin_fmaxf(fly, -2.0f), c.fih);
+                        const int off = iy * rs + ix;
+                        const float* p = a.ref.I + off;
+                        i00 = p[0]; i01 = p[1]; i10 = p[rs]; i11 = p[rs + 1];
+                        const float* px = a.ref.gx + off;
+                        x00 = px[0]; x01 = px[1]; x10 = px[rs]; x11 = px[rs + 1];
+                        const float* py = a.ref.gy + off;
+                        y00 = py[0]; y01 = py[1]; y10 = py[rs]; y11 = py[rs + 1];
+                    }
+                    const float Iw = bilerp4(i00, i01, i10, i11, ax, ay);
+                    const float gxw = bilerp4(x00, x01, x10, x11, ax, ay);
+                    const float gyw = bilerp4(y00, y01, y10, y11, ax, ay);
+                    accumulate_pixel<MOTION, NS>(c, sl->warp, x, y, fx, fy, sx, sy, rden, hx, hy, Iw, gxw, gyw, tval, acc);
+                }
+            }
+            if (!has_next) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed ...
+            __syncthreads();                                   // ... and so has every other wave's
+            cur = nxt; tile = next; b ^= 1;
+        }
+    }
+    __syncthreads();
+    block_reduce_store<NS>(acc, a, slot, region);
+}
+
+hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
+    if (variant == 1) {
+        const size_t lds_bytes = 2 * BUF_FLOATS * sizeof(float);
+        switch (motion) {
+            case STK_MOTION_HOMOGRAPHY: ecc_iter_tiled_kernel<STK_MOTION_HOMOGRAPHY><<<grid, 256, lds_bytes, s>>>(a); break;
+            case STK_MOTION_AFFINE: ecc_iter_tiled_kernel<STK_MOTION_AFFINE><<<grid, 256, lds_bytes, s>>>(a); break;
+            case STK_MOTION_EUCLIDEAN: ecc_iter_tiled_kernel<STK_MOTION_EUCLIDEAN><<<grid, 256, lds_bytes, s>>>(a); break;
+            case STK_MOTION_TRANSLATION: ecc_iter_tiled_kernel<STK_MOTION_TRANSLATION><<<grid, 256, lds_bytes, s>>>(a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (motion) {
         case STK_MOTION_HOMOGRAPHY: ecc_iter_kernel<STK_MOTION_HOMOGRAPHY><<<grid, 256, 0, s>>>(a); break;
         case STK_MOTION_AFFINE: ecc_iter_kernel<STK_MOTION_AFFINE><<<grid, 256, 0, s>>>(a); break;

@@ -122,6 +122,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
+    else if (n == "ecc_variant") { if (value != 0 && value != 1) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0 or 1"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;
@@ -175,13 +176,15 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     }
     pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
     // blocks per slot: multiple of 8 (XCD-aware decode), each block = 4 waves = 4 rows per sweep
-    const int row_groups = (h + 3) / 4;
-    int nb = std::max(8, std::min(row_groups, ctx->opt_ecc_blocks / pl.n_slots));
+    // work units of one slot: 4-row groups (direct variant) or 64x16 tiles (tiled variant)
+    const int units = ctx->opt_ecc_variant == 1 ? ((w + ECC_TILE_W - 1) / ECC_TILE_W) * ((h + ECC_TILE_H - 1) / ECC_TILE_H) : (h + 3) / 4;
+    int nb = std::max(8, std::min(units, ctx->opt_ecc_blocks / pl.n_slots));
     nb = std::max(8, (nb / 8) * 8);
     pl.nb = nb;
     HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 3 * sizeof(float)));
     HIP_TRY(ctx->blur_tmp.reserve(pl.templ_plane_stride * sizeof(float)));
-    HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1)));
+    // + slack: the tiled kernel copies whole 64-float tile rows, which may run past the last row's end
+    HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1) + 1024));
     HIP_TRY(ctx->slots.reserve(sizeof(EccSlot) * pl.n_slots));
     HIP_TRY(ctx->queue.reserve(sizeof(EccQueue)));
     HIP_TRY(ctx->results.reserve(sizeof(EccFrameResult) * std::max(n_templates, 1)));
@@ -238,7 +241,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                 for (int c = 0; c < chunk; c++) {
                     const bool timed = ctx->opt_profile >= 2 && prof_used + 2 <= ctx->prof_ev.size();
                     if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used], ctx->stream));
-                    HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->stream));
+                    HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->opt_ecc_variant, ctx->stream));
                     if (timed) { HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used + 1], ctx->stream)); prof_used += 2; }
                     HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
                 }
