@@ -30,7 +30,7 @@ struct stk_ctx {
     int opt_subpixel_bits = 0;
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
-    int opt_ecc_blocks = 2048;    // total workgroups of one ECC iteration launch (all slots)
+    int opt_ecc_blocks = 768;     // total workgroups of one ECC iteration launch (all slots)
     int opt_ecc_variant = 0;      // 0 = direct gathers (faster as measured, r01), 1 = LDS-tiled iteration kernel
     stk_timing timing{};
     hipEvent_t ev[8] = {};

@@ -248,6 +248,54 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// row-sharing variant: the waves of a workgroup are the SLOTS. All of them process the same template
+// row at the same time on the same CU, each with its own frame and warp, so the frame-0 taps that
+// the near-identical warps share are fetched once and then hit in that CU's L1 (measured with the
+// direct variant: the fabric-side read traffic equals the algorithmic 16 B/px, i.e. every slot
+// re-fetches frame 0; here it approaches 4 B/px + 12 B/px / n_slots). No LDS, no barrier: a wave
+// reduces its own 66 sums and writes its slot's partial.
+// ---------------------------------------------------------------------------------------------------
+template <int MOTION>
+__global__ __launch_bounds__(512) void ecc_iter_rows_kernel(EccIterArgs a) {
+    constexpr int P = MotionTraits<MOTION>::P;
+    constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
+    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const EccSlot* sl = a.slots + slot;
+    const int frame = sl->frame;
+    if (frame < 0) return;                                    // idle slot: this wave leaves (no barriers below)
+    SlotConst c;
+    load_slot_const(sl, a, c);
+    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
+    float acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) acc[k] = 0.f;
+    // blocks that share an XCD (blockIdx % 8) take a contiguous band of rows: the frame-0 row shared by
+    // template rows y and y+1 is then an L2 hit for the neighbouring block
+    const int nb = gridDim.x, per = nb >> 3;
+    const int first = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int qw = (a.tw + 3) >> 2;
+    for (int y = first; y < a.th; y += nb) {
+        const float* trow = T + (size_t)y * a.templ_row_stride;
+        for (int qx = lane; qx < qw; qx += 64) {
+            const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                const int x = qx * 4 + j;
+                const float tvj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
+                if (x < a.tw) pixel_direct<MOTION, NS>(c, a, sl->warp, x, y, tvj, acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == (k & 63)) a.partials[((size_t)slot * NS + k) * a.nb + blockIdx.x] = (double)v;   // [slot][sum][block]
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // tiled variant: 64 x 16 pixel tiles, source footprint double-buffered in LDS
 // ---------------------------------------------------------------------------------------------------
 constexpr int TILE_W = 64, TILE_H = 16;
@@ -416,6 +464,17 @@ __global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
 
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
+    if (variant == 2) {     // one workgroup = n_slots waves; a.nb workgroups in total (multiple of 8)
+        const int threads = 64 * a.n_slots;
+        switch (motion) {
+            case STK_MOTION_HOMOGRAPHY: ecc_iter_rows_kernel<STK_MOTION_HOMOGRAPHY><<<a.nb, threads, 0, s>>>(a); break;
+            case STK_MOTION_AFFINE: ecc_iter_rows_kernel<STK_MOTION_AFFINE><<<a.nb, threads, 0, s>>>(a); break;
+            case STK_MOTION_EUCLIDEAN: ecc_iter_rows_kernel<STK_MOTION_EUCLIDEAN><<<a.nb, threads, 0, s>>>(a); break;
+            case STK_MOTION_TRANSLATION: ecc_iter_rows_kernel<STK_MOTION_TRANSLATION><<<a.nb, threads, 0, s>>>(a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (variant == 1) {
         const size_t lds_bytes = 2 * BUF_FLOATS * sizeof(float);
         switch (motion) {

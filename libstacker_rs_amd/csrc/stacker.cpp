@@ -122,7 +122,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
-    else if (n == "ecc_variant") { if (value != 0 && value != 1) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0 or 1"); ctx->opt_ecc_variant = (int)value; }
+    else if (n == "ecc_variant") { if (value < 0 || value > 2) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0, 1 or 2"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;
@@ -179,6 +179,12 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     // work units of one slot: 4-row groups (direct variant) or 64x16 tiles (tiled variant)
     const int units = ctx->opt_ecc_variant == 1 ? ((w + ECC_TILE_W - 1) / ECC_TILE_W) * ((h + ECC_TILE_H - 1) / ECC_TILE_H) : (h + 3) / 4;
     int nb = std::max(8, std::min(units, ctx->opt_ecc_blocks / pl.n_slots));
+    if (ctx->opt_ecc_variant == 2) {
+        // row-sharing variant: a workgroup = n_slots waves (one per slot) on one template row; as many
+        // workgroups as keep the same number of waves in flight as the other variants
+        pl.n_slots = std::min(pl.n_slots, 8);
+        nb = std::max(8, std::min(h, ctx->opt_ecc_blocks * 4 / pl.n_slots));
+    }
     nb = std::max(8, (nb / 8) * 8);
     pl.nb = nb;
     HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 3 * sizeof(float)));
