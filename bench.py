@@ -169,9 +169,21 @@ def main() -> None:
             launches = agg["ecc_iter_timed"]
             avg_ms = agg["ecc_iter_ms"] / launches
             achieved = alg_bytes_total / (agg["ecc_iter_ms"] * 1e-3) / 1e9
+            # HBM-side traffic per launch from the PMC passes of the SAME command (tools/profile_round.sh,
+            # separate FETCH_SIZE / WRITE_SIZE passes; summary committed under profiles/): FETCH_SIZE is
+            # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 (the float4 scale_kernel in the same
+            # run calibrates exactly 1/2), WRITE_SIZE is taken as reported. null if no summary is present.
+            traffic = None
+            if args.workload == "ecc_4k" and world == 1 and not args.opt and not args.ecc_slots:
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))["stk::ecc_iter_kernel<3>"]
+                    traffic = round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1)
+                except Exception:
+                    traffic = None
             res["roofline"] = {"kernel": "ecc_iter_kernel<HOMOGRAPHY>", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": None, "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                               "traffic": traffic, "traffic_source": "rocprofv3 --pmc (profiles/r01/pmc_summary.json)" if traffic else None,
+                               "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                                "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
         its = [s["iterations"] for s in (last_stats or [])[1:]]
         src_b = 3 * px

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstacker_amd.so")
+LIB_PATH = os.environ.get("STACKER_AMD_LIB") or os.path.join(_HERE, "libstacker_amd.so")   # override: A/B builds
 
 c_status = C.c_int
 

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
         const float* trow = T + (size_t)y * a.templ_row_stride;
         for (int qx = lane; qx < qw; qx += 64) {
             const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
-#pragma unroll 1
+#pragma unroll 2
             for (int j = 0; j < 4; j++) {
                 const int x = qx * 4 + j;
                 const float tvj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void ecc_iter_rows_kernel(EccIterArgs a) {
         const float* trow = T + (size_t)y * a.templ_row_stride;
         for (int qx = lane; qx < qw; qx += 64) {
             const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
-#pragma unroll 1
+#pragma unroll 2
             for (int j = 0; j < 4; j++) {
                 const int x = qx * 4 + j;
                 const float tvj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
