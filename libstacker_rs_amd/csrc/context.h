@@ -31,7 +31,8 @@ struct stk_ctx {
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
     int opt_ecc_blocks = 768;     // total workgroups of one ECC iteration launch (all slots)
-    int opt_ecc_variant = 0;      // 0 = direct gathers (faster as measured, r01), 1 = LDS-tiled iteration kernel
+    int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = row-factorised Hessian (homography, default), 0 = direct gathers,
+                                  // 1 = LDS-tiled (LDS-DMA), 2 = row-sharing slots; see kernels_ecc.hip
     stk_timing timing{};
     hipEvent_t ev[8] = {};
     hipEvent_t poll_ev[2] = {};

@@ -8,14 +8,19 @@
 //  partials. OpenCV materialises ~150 f32 planes per iteration for the same result; here the
 //  algorithmic traffic is 16 B/px.
 //
-//  Two variants of the pass, same arithmetic per pixel (bit-identical results):
-//   * tiled (default): a workgroup walks 64x16-pixel tiles. The source footprint of a tile (the
-//     bounding box of its four warped corners, + margin) is staged in LDS for all three planes,
-//     double-buffered: the global loads of tile k+1 are issued before tile k is computed and written
-//     to the other LDS buffer afterwards, so HBM/L2 latency hides behind ~1000 px of arithmetic and
-//     every tap is an LDS read. Tiles whose footprint does not fit (large rotations / zooms) fall
-//     back to direct gathers.
-//   * direct: every tap is a global gather (L1/L2 absorb the overlap between neighbouring lanes).
+//  Three variants of the pass, same arithmetic per pixel (they differ in the f32 summation order only):
+//   * direct (variant 0, default — fastest as measured in round 1): one wave per template row, lanes
+//     stream aligned 16-byte template quads, every tap is a global gather; the overlap between
+//     neighbouring lanes and rows is absorbed by L1/L2.
+//   * tiled (variant 1): a workgroup walks 64x16-pixel tiles; the source footprint of a tile (bounding
+//     box of its four warped corners + margin) is copied for all three planes into LDS with LDS-DMA
+//     (global_load_lds_dwordx4), double-buffered, and every tap is an LDS read. Tiles whose
+//     footprint does not fit (large rotations / zooms) gather directly.
+//   * row-sharing (variant 2): the waves of a workgroup are the slots, all on the same template row.
+//  Measured (profiles/r01): the pass is bound by VALU issue with ~3 resident waves per
+//  SIMD (142 VGPRs: 66 accumulators), not by HBM or gather latency — staging through LDS, sharing
+//  rows between slots and prefetching the template each left the time unchanged or worse, while
+//  removing 35 of the ~126 VALU instructions per pixel scaled the time proportionally.
 //
 //  Several frames ("slots") iterate concurrently in one launch. blockIdx is decoded so that the
 //  blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD and
@@ -47,7 +52,7 @@ __device__ __forceinline__ int sat_round_d(double v) {
 // The mask pixel exactly as the classic INTER_NEAREST remap path computes it (imgwarp.cpp):
 // homography: double coordinates, cvRound; affine family: AB_BITS = 10 fixed point.
 template <int MOTION>
-__device__ __noinline__ bool nearest_inside_exact(int x, int y, const float* m, int iw, int ih) {
+__device__ __forceinline__ bool nearest_inside_exact(int x, int y, const float* m, int iw, int ih) {
     int mx, my;
     if constexpr (MOTION == STK_MOTION_HOMOGRAPHY) {
         double W = (double)m[6] * x + (double)m[7] * y + (double)m[8];
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
     const int qw = (a.tw + 3) >> 2;                           // quads per row
     for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
         const float* trow = T + (size_t)y * a.templ_row_stride;
+        // (prefetching the template quads two iterations ahead in registers was measured: no gain, r01)
         for (int qx = lane; qx < qw; qx += 64) {
             const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
 #pragma unroll 2
@@ -245,6 +251,150 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
         }
     }
     block_reduce_store<NS>(acc, a, slot, region);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// homography, row-factorised Hessian (variant 3). The pass is bound by VALU issue with few resident
+// waves (66 accumulators per lane), so this variant removes both work and registers:
+//   J = (a, b, t) (x) (X, Y, 1) minus t.1, hence every Hessian entry is  sum q * X^i * Y^j  with
+//   q in {aa, ab, at, bb, bt, tt}. Y is constant along a template row, so a lane only accumulates the
+//   18 X-moments  sum q*X^2, sum q*X, sum q  of its row (18 FMAs per pixel instead of 36). At the end of
+//   the row the wave reduces them with shuffles and lane L < 36 folds "its" entry, scaled by Y^j, into
+//   ONE f64 accumulator — the 36 long-lived per-lane f32 accumulators disappear.
+// Same sums as the other variants up to f32 rounding (products are associated differently).
+// ---------------------------------------------------------------------------------------------------
+// packed upper-triangular entry (row-major, J order aX bX tX aY bY tY a b) -> X-moment index, power of Y
+__constant__ unsigned char c_hess_src[36] = {0, 1, 2, 6, 7, 8, 6, 7,  3, 4, 7, 9, 10, 7, 9,  5, 8, 10, 11, 8, 10,
+                                              12, 13, 14, 12, 13,  15, 16, 13, 15,  17, 14, 16,  12, 13,  15};
+__constant__ unsigned char c_hess_ypow[36] = {0, 0, 0, 1, 1, 1, 0, 0,  0, 0, 1, 1, 1, 0, 0,  0, 1, 1, 1, 0, 0,
+                                               2, 2, 2, 1, 1,  2, 2, 1, 1,  2, 1, 1,  0, 0,  0};
+
+__global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   // 4 waves/SIMD: <= 128 VGPRs
+    constexpr int MOTION = STK_MOTION_HOMOGRAPHY;
+    constexpr int P = 8, NH = 36, NR = 3 * P + 6, NS = NH + NR;   // NR = 30 per-lane sums besides the Hessian
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int slot = q % a.n_slots;
+    const int region = (q / a.n_slots) * 8 + xcd;
+    const EccSlot* sl = a.slots + slot;
+    const int frame = sl->frame;
+    if (frame < 0) return;
+    SlotConst c;
+    load_slot_const(sl, a, c);
+    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hsrc = c_hess_src[min(lane, 35)], hyp = c_hess_ypow[min(lane, 35)];
+
+    float acc[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) acc[k] = 0.f;
+    double hacc = 0.0;                                        // lane L < 36: Hessian entry L
+    const int rs = a.ref.stride;
+    const int qw = (a.tw + 3) >> 2;
+    for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
+        const float fy = (float)y;
+        const float rowX = __builtin_fmaf(c.m1, fy, c.m2), rowY = __builtin_fmaf(c.m4, fy, c.m5);
+        const float rowW = __builtin_fmaf(c.m7, fy, c.m8);   // m22 == 1 is guaranteed by the launcher (den == w)
+        float h2[6], h1[6], h0[6];                            // sum q*X^2, sum q*X, sum q over this lane's pixels of the row
+#pragma unroll
+        for (int k = 0; k < 6; k++) { h2[k] = 0.f; h1[k] = 0.f; h0[k] = 0.f; }
+        const float* trow = T + (size_t)y * a.templ_row_stride;
+        for (int qx = lane; qx < qw; qx += 64) {
+            const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
+#pragma unroll 2
+            for (int j = 0; j < 4; j++) {
+                const int x = qx * 4 + j;
+                const float tval = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
+                if (x < a.tw) {
+                    const float fx = (float)x;
+                    float sx = __builtin_fmaf(c.m0, fx, rowX), sy = __builtin_fmaf(c.m3, fx, rowY);
+                    const float rw = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m6, fx, rowW));
+                    const float rden = rw;
+                    const float hx = -sx * rden, hy = -sy * rden;
+                    sx *= rw; sy *= rw;
+                    const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
+                    const float ax = sx - flx, ay = sy - fly;
+                    const int ix = (int)__builtin_fminf(__builtin_fmaxf(flx, -2.0f), c.fiw);
+                    const int iy = (int)__builtin_fminf(__builtin_fmaxf(fly, -2.0f), c.fih);
+                    const int off = iy * rs + ix;
+                    const f32x2_a4 i0 = *(const f32x2_a4*)(a.ref.I + off), i1 = *(const f32x2_a4*)(a.ref.I + off + rs);
+                    const f32x2_a4 x0 = *(const f32x2_a4*)(a.ref.gx + off), x1 = *(const f32x2_a4*)(a.ref.gx + off + rs);
+                    const f32x2_a4 y0 = *(const f32x2_a4*)(a.ref.gy + off), y1 = *(const f32x2_a4*)(a.ref.gy + off + rs);
+                    const float Iw = bilerp4(i0.x, i0.y, i1.x, i1.y, ax, ay);
+                    const float gxw = bilerp4(x0.x, x0.y, x1.x, x1.y, ax, ay);
+                    const float gyw = bilerp4(y0.x, y0.y, y1.x, y1.y, ax, ay);
+                    bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
+                    if (!inside) {
+                        const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
+                        inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
+                        const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
+                                          (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
+                        if (edge) inside = nearest_inside_exact<MOTION>(x, y, sl->warp, c.iw, c.ih);
+                    }
+                    const float mf = inside ? 1.0f : 0.0f;
+                    const float ja = gxw * rden, jb = gyw * rden;
+                    const float jt = hx * ja + hy * jb;
+                    // Hessian: X-moments of the six products
+                    const float qv[6] = {ja * ja, ja * jb, ja * jt, jb * jb, jb * jt, jt * jt};
+                    const float xx = fx * fx;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        h2[k] = __builtin_fmaf(qv[k], xx, h2[k]);
+                        h1[k] = __builtin_fmaf(qv[k], fx, h1[k]);
+                        h0[k] += qv[k];
+                    }
+                    const float J[8] = {ja * fx, jb * fx, jt * fx, ja * fy, jb * fy, jt * fy, ja, jb};
+                    const float u = inside ? Iw - c.cI : Iw;
+                    const float v = inside ? tval - c.cT : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < P; k++) {
+                        acc[k] = __builtin_fmaf(J[k], u, acc[k]);
+                        acc[P + k] = __builtin_fmaf(J[k], v, acc[P + k]);
+                        acc[2 * P + k] = __builtin_fmaf(J[k], mf, acc[2 * P + k]);
+                    }
+                    const float um = u * mf;
+                    acc[3 * P + 0] += mf;
+                    acc[3 * P + 1] += um;
+                    acc[3 * P + 2] = __builtin_fmaf(um, u, acc[3 * P + 2]);
+                    acc[3 * P + 3] += v;
+                    acc[3 * P + 4] = __builtin_fmaf(v, v, acc[3 * P + 4]);
+                    acc[3 * P + 5] = __builtin_fmaf(um, v, acc[3 * P + 5]);
+                }
+            }
+        }
+        // end of row: wave-reduce the 18 X-moments, then lane L < 36 takes entry L times Y^j in f64
+        float sel = 0.f;
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+            float r = k < 6 ? h2[k] : k < 12 ? h1[k - 6] : h0[k - 12];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+            sel = (hsrc == k) ? r : sel;
+        }
+        const double dy = (double)fy;
+        hacc += (double)sel * (hyp == 0 ? 1.0 : hyp == 1 ? dy : dy * dy);
+    }
+
+    // block reduction: the 30 per-lane sums by shuffles, the 36 Hessian entries are already one per lane
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        float r = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+        acc[k] = r;
+    }
+    __shared__ double red[4][NS];
+    if (lane < NH) red[wave][lane] = hacc;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) red[wave][NH + k] = (double)acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        const int k = threadIdx.x;
+        const double s = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+        a.partials[((size_t)slot * NS + k) * a.nb + region] = s;   // [slot][sum][block]
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -464,6 +614,10 @@ __global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
 
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
+    if (variant == 3 && motion == STK_MOTION_HOMOGRAPHY) {   // other motions: direct variant below
+        ecc_iter_h8_kernel<<<grid, 256, 0, s>>>(a);
+        return hipGetLastError();
+    }
     if (variant == 2) {     // one workgroup = n_slots waves; a.nb workgroups in total (multiple of 8)
         const int threads = 64 * a.n_slots;
         switch (motion) {

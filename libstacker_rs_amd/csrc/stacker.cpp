@@ -122,7 +122,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
-    else if (n == "ecc_variant") { if (value < 0 || value > 2) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0, 1 or 2"); ctx->opt_ecc_variant = (int)value; }
+    else if (n == "ecc_variant") { if (value < 0 || value > 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0..3"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;
@@ -527,9 +527,12 @@ stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* i
         t = ctx->frames.p; in = ctx->frames.as<uint8_t>() + ib;
     }
     EccPlan pl{};
-    const int saved_slots = ctx->opt_ecc_slots;
-    if ((st = ecc_plan(ctx, width, height, 1, params->motion_type, pl))) return st;
-    (void)saved_slots;
+    // variant 3 assumes m22 == 1 (true for every warp findTransformECC itself produces); a caller-supplied
+    // initial warp with another m22 takes the general kernel
+    const int saved_variant = ctx->opt_ecc_variant;
+    if (saved_variant == 3 && params->motion_type == STK_MOTION_HOMOGRAPHY && warp[8] != 1.0f) ctx->opt_ecc_variant = 0;
+    st = ecc_plan(ctx, width, height, 1, params->motion_type, pl);
+    if (st) { ctx->opt_ecc_variant = saved_variant; return st; }
     const size_t rb = (size_t)width * (depth / 8);
     if ((st = ecc_prepare_reference(ctx, pl, in, depth, 1, rb, params->gauss_filt_size))) return st;
     HIP_TRY(launch_grey_blur(t, depth, 1, width, height, rb, params->gauss_filt_size, ctx->templates.as<float>(), pl.templ_row_stride, ctx->stream));
@@ -540,7 +543,9 @@ stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* i
     HIP_TRY(hipMemcpyAsync(ctx->init_warps.p, w9, sizeof(w9), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<EccFrameResult> res;
-    if ((st = ecc_run(ctx, pl, crit, ctx->init_warps.as<float>(), res))) return st;
+    st = ecc_run(ctx, pl, crit, ctx->init_warps.as<float>(), res);
+    ctx->opt_ecc_variant = saved_variant;
+    if (st) return st;
     if (crit.n_iter >= 1) for (int k = 0; k < 9; k++) warp[k] = res[0].warp[k];
     if (rho) *rho = res[0].rho;
     if (iterations) *iterations = res[0].iters;

@@ -133,13 +133,17 @@ def test_tiled_lds_variant_agrees_with_direct(stacker, small_stack):
         Wt, rho_t, _ = stacker.find_transform_ecc(g0, g0, big, p1)
         stacker.set_option("ecc_variant", 2)       # row-sharing variant: waves of a workgroup = slots
         out2, s2 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
+        stacker.set_option("ecc_variant", 0)       # direct gathers, 66 per-lane accumulators
+        out0, s3 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
     finally:
-        stacker.set_option("ecc_variant", 0)
+        stacker.set_option("ecc_variant", 3)       # default: row-factorised Hessian
     Wd, rho_d, _ = stacker.find_transform_ecc(g0, g0, big, p1)
-    for a, b, c in zip(s0[1:], s1[1:], s2[1:]):
+    for a, b, c, d in zip(s0[1:], s1[1:], s2[1:], s3[1:]):
         assert abs(a["iterations"] - b["iterations"]) <= 1 and abs(a["iterations"] - c["iterations"]) <= 1
+        assert abs(a["iterations"] - d["iterations"]) <= 1
         assert synth.corner_error(a["warp"], b["warp"], 320, 240) <= 0.02
         assert synth.corner_error(a["warp"], c["warp"], 320, 240) <= 0.02
+        assert synth.corner_error(a["warp"], d["warp"], 320, 240) <= 0.02
     assert abs(rho_t - rho_d) <= 1e-6 and np.allclose(Wt, Wd, rtol=0, atol=1e-4)
 
 
