@@ -77,9 +77,19 @@ struct EccIterArgs {
     int templ_row_stride;        // floats per template row (multiple of 4)
     int tw, th;
     EccSlot* slots;
-    int n_slots;
+    int n_slots;                 // slots iterated by this launch: slot0 .. slot0 + n_slots - 1
     int nb;                      // blocks per slot (multiple of 8)
-    double* partials;            // [n_slots][nsums][nb]
+    double* partials;            // [all slots][nsums][nb]
+    // fused launches (variants 0 and 3): the slots are split in two groups that alternate; while one group's
+    // pixel pass runs, `solve_n` extra workgroups solve the OTHER group's previous pass (its partials are
+    // complete: they were written by the previous launch), so the solve latency is hidden.
+    int slot0;
+    int solve_slot0, solve_n;
+    int motion;
+    EccCriteria crit;
+    EccQueue* queue;
+    EccFrameResult* results;
+    const float* init_warps;
 };
 
 struct WarpFrame {

@@ -1,0 +1,235 @@
+// ecc_solve_body.h — the per-iteration "solve" step of findTransformECC as a device routine (see
+// kernels_ecc_solve.hip for the description). Shared by the stand-alone solve kernel and the fused
+// iteration kernels, which run it in a few extra workgroups next to the next group's pixel pass.
+#pragma once
+#include "common.h"
+
+namespace stk {
+
+__device__ inline void slot_take_next(EccSlot* sl, EccQueue* queue, const float* init_warps) {
+    const int nxt = atomicAdd(&queue->next_frame, 1);
+    if (nxt < queue->n_frames) {
+        sl->frame = nxt;
+        sl->iter = 0;
+        for (int k = 0; k < 9; k++) sl->warp[k] = init_warps ? init_warps[(size_t)nxt * 9 + k] : ((k % 4 == 0) ? 1.f : 0.f);
+        sl->cI = 0; sl->cT = 0;
+        sl->rho = -1;
+    } else {
+        sl->frame = -1;
+    }
+}
+
+// cv::invert(DECOMP_LU) closed forms for CV_32F 2x2 / 3x3 (evaluated in double), serial.
+__device__ inline void invert_small_f32(const float* S, int n, float* D) {
+    if (n == 2) {
+        double d = (double)S[0] * S[3] - (double)S[1] * S[2];
+        if (d != 0.) {
+            d = 1. / d;
+            D[3] = (float)(S[0] * d); D[0] = (float)(S[3] * d);
+            D[1] = (float)(-S[1] * d); D[2] = (float)(-S[2] * d);
+        } else { for (int i = 0; i < 4; i++) D[i] = 0; }
+        return;
+    }
+    const double s00 = S[0], s01 = S[1], s02 = S[2], s10 = S[3], s11 = S[4], s12 = S[5], s20 = S[6], s21 = S[7], s22 = S[8];
+    double d = s00 * (s11 * s22 - s12 * s21) - s01 * (s10 * s22 - s12 * s20) + s02 * (s10 * s21 - s11 * s20);
+    if (d != 0.) {
+        d = 1. / d;
+        D[0] = (float)((s11 * s22 - s12 * s21) * d); D[1] = (float)((s02 * s21 - s01 * s22) * d);
+        D[2] = (float)((s01 * s12 - s02 * s11) * d); D[3] = (float)((s12 * s20 - s10 * s22) * d);
+        D[4] = (float)((s00 * s22 - s02 * s20) * d); D[5] = (float)((s02 * s10 - s00 * s12) * d);
+        D[6] = (float)((s10 * s21 - s11 * s20) * d); D[7] = (float)((s01 * s20 - s00 * s21) * d);
+        D[8] = (float)((s00 * s11 - s01 * s10) * d);
+    } else { for (int i = 0; i < 9; i++) D[i] = 0; }
+}
+
+// One workgroup of SOLVE_WAVES wavefronts solves one slot. Called by the stand-alone solve kernel (16 waves)
+// and, with 4 waves, by the extra workgroups of the fused iteration kernels (kernels_ecc.hip).
+template <int SOLVE_WAVES>
+__device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, int motion, EccCriteria crit, EccQueue* queue,
+                                               EccFrameResult* results, const float* init_warps) {
+    EccSlot* sl = a.slots + slot;
+    const int frame = sl->frame;
+    if (frame < 0) return;
+    const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
+    const int NH = P * (P + 1) / 2, NS = NH + 3 * P + 6;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    __shared__ double S[ECC_MAX_SUMS];
+    __shared__ float AB[8][16];          // [A | B] of the LU inverse, B starts as I
+    __shared__ float Hinv[64];
+    __shared__ float vec[4][8];          // ipf, tpf, iph, epf
+    __shared__ double dvec[2][8];        // ipd, tpd
+
+    // ---- 1. reduce block partials: 16 waves, wave w owns sums w, w+16, ...; all loads of a wave are
+    //         issued before the first add so the HBM round trips overlap --------------------------------
+    const double* base = a.partials + (size_t)slot * NS * a.nb;
+    {
+        constexpr int KR = (ECC_MAX_SUMS + SOLVE_WAVES - 1) / SOLVE_WAVES;     // sums per wave (<= 5)
+        double acc[KR];
+#pragma unroll
+        for (int r = 0; r < KR; r++) acc[r] = 0;
+        for (int b = lane; b < a.nb; b += 64) {
+#pragma unroll
+            for (int r = 0; r < KR; r++) {
+                const int k = wave + SOLVE_WAVES * r;
+                if (k < NS) acc[r] += base[(size_t)k * a.nb + b];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < KR; r++) {
+            double v = acc[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int k = wave + SOLVE_WAVES * r;
+            if (lane == 0 && k < NS) S[k] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. statistics (every thread computes the same scalars; no divergence) ------------------
+    const double cI = sl->cI, cT = sl->cT;
+    const double* ST = S + NH + 3 * P;
+    const double n = ST[0];
+    const double mu = n > 0 ? ST[1] / n : 0, mv = n > 0 ? ST[3] / n : 0;   // means of the centred samples
+    const double imgMean = cI + mu, tmpMean = cT + mv;
+    const double imgVar = n > 0 ? fmax(ST[2] / n - mu * mu, 0.) : 0;
+    const double tmpVar = n > 0 ? fmax(ST[4] / n - mv * mv, 0.) : 0;
+    const double imgStd = sqrt(imgVar), tmpStd = sqrt(tmpVar);
+    const double imgNorm = sqrt(n * imgStd * imgStd), tmpNorm = sqrt(n * tmpStd * tmpStd);
+    // OpenCV subtracts the means cast to f32 (arithm_op's scalar path); dI/dT are those casts relative
+    // to the centring offsets the iteration kernel used.
+    const float imgMeanF = (float)imgMean, tmpMeanF = (float)tmpMean;
+    const double dI = (double)imgMeanF - cI, dT = (double)tmpMeanF - cT;
+    const double correlation = ST[5] - dT * ST[1] - dI * ST[3] + n * dT * dI;
+
+    if (tid < P) {
+        const double jm = S[NH + 2 * P + tid];
+        const double ipd = S[NH + tid] - dI * jm;          // sum J.(Iw - mean.m)
+        const double tpd = S[NH + P + tid] - dT * jm;      // sum J.(T - mean).m
+        dvec[0][tid] = ipd; dvec[1][tid] = tpd;
+        vec[0][tid] = (float)ipd; vec[1][tid] = (float)tpd;
+    }
+    // Hessian (upper triangle packed row-major) -> symmetric f32 matrix, augmented with I
+    if (tid < P * 2 * P) {
+        const int r = tid / (2 * P), c = tid - r * 2 * P;
+        float v;
+        if (c < P) {
+            const int i = min(r, c), j = max(r, c);
+            v = (float)S[i * P - i * (i - 1) / 2 + (j - i)];
+        } else v = (c - P == r) ? 1.f : 0.f;
+        AB[r][c] = v;
+    }
+    __syncthreads();
+
+    // ---- 3. inverse ------------------------------------------------------------------------------
+    if (P <= 3) {
+        if (tid == 0) {
+            float Sm[9];
+            for (int r = 0; r < P; r++) for (int c = 0; c < P; c++) Sm[r * P + c] = AB[r][c];
+            invert_small_f32(Sm, P, Hinv);
+        }
+    } else if (wave == 0) {
+        // hal::LU32f on [A | I]: one wavefront, each lane owns up to two elements of the P x 2P array.
+        // Per pivot step every element is rewritten from a snapshot of the previous state, which is the
+        // serial loop's arithmetic element by element (swap rows i,k; row j += (A[j][i] * -1/A[i][i]) * row i).
+        const float eps = 1.1920929e-07f * 10;
+        const int W2 = 2 * P, NE = P * W2;
+        bool singular = false;
+        for (int i = 0; i < P && !singular; i++) {
+            int k = i;                                             // partial pivoting: strict '>' keeps the first maximum
+            float best = fabsf(AB[i][i]);
+            for (int j = i + 1; j < P; j++) { const float v = fabsf(AB[j][i]); if (v > best) { best = v; k = j; } }
+            if (best < eps) { singular = true; break; }
+            const float d = -1 / AB[k][i];
+            float nv[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int t = lane + 64 * e;
+                const int r = t / W2, c = t - r * W2;
+                float v = 0;
+                if (t < NE) {
+                    const int src = (r == i) ? k : (r == k) ? i : r;   // row that sits in row r after the swap
+                    v = AB[src][c];
+                    if (r > i && c > i) v = v + (AB[src][i] * d) * AB[k][c];
+                }
+                nv[e] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 2; e++) { const int t = lane + 64 * e; if (t < NE) AB[t / W2][t % W2] = nv[e]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!singular) {
+            if (lane < P) {                                        // back substitution, one B column per lane
+                const int j = P + lane;
+                for (int i = P - 1; i >= 0; i--) {
+                    float sacc = AB[i][j];
+                    for (int k = i + 1; k < P; k++) sacc -= AB[i][k] * AB[k][j];
+                    AB[i][j] = sacc / AB[i][i];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < P * P) Hinv[lane] = AB[lane / P][P + lane % P];
+        } else if (lane < P * P) Hinv[lane] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- 4. lambda, parameter update, loop control -------------------------------------------------
+    if (tid < P) { float s = 0; for (int l = 0; l < P; l++) s += Hinv[tid * P + l] * vec[0][l]; vec[2][tid] = s; }   // iph
+    __syncthreads();
+    if (tid != 0) return;
+
+    const double last_rho = sl->rho;
+    double rho = correlation / (imgNorm * tmpNorm);
+    const int iter = sl->iter + 1;
+    int status = 0;
+    bool finished = false;
+    if (rho != rho) { status = 1; finished = true; }
+    else {
+        double dot_ip = 0, dot_tp = 0;
+        for (int k = 0; k < P; k++) { dot_ip += (double)vec[0][k] * vec[2][k]; dot_tp += (double)vec[1][k] * vec[2][k]; }
+        const double lambda_n = imgNorm * imgNorm - dot_ip;
+        const double lambda_d = correlation - dot_tp;
+        if (lambda_d <= 0.0) { rho = -1; status = 2; finished = true; }
+        else {
+            const float lamf = (float)(lambda_n / lambda_d);
+            float epf[8], dp[8];
+            for (int k = 0; k < P; k++) epf[k] = (float)((double)lamf * dvec[1][k] - dvec[0][k]);
+            for (int k = 0; k < P; k++) { float s = 0; for (int l = 0; l < P; l++) s += Hinv[k * P + l] * epf[l]; dp[k] = s; }
+            float* m = sl->warp;
+            if (motion == STK_MOTION_HOMOGRAPHY) {
+                m[0] += dp[0]; m[3] += dp[1]; m[6] += dp[2]; m[1] += dp[3]; m[4] += dp[4]; m[7] += dp[5]; m[2] += dp[6]; m[5] += dp[7];
+            } else if (motion == STK_MOTION_AFFINE) {
+                m[0] += dp[0]; m[3] += dp[1]; m[1] += dp[2]; m[4] += dp[3]; m[2] += dp[4]; m[5] += dp[5];
+            } else if (motion == STK_MOTION_TRANSLATION) {
+                m[2] += dp[0]; m[5] += dp[1];
+            } else {
+                const double th = (double)dp[0] + asin((double)m[3]);
+                m[2] += dp[1]; m[5] += dp[2];
+                m[0] = m[4] = (float)cos(th);
+                m[3] = (float)sin(th);
+                m[1] = -m[3];
+            }
+        }
+    }
+    // for (i = 1; i <= nIter && fabs(rho - last_rho) >= eps; i++): would iteration iter+1 run?
+    if (!finished) finished = (iter + 1 > crit.n_iter) || !(fabs(rho - last_rho) >= crit.eps);
+    sl->iter = iter;
+    sl->last_rho = last_rho;
+    sl->rho = rho;
+    sl->cI = imgMeanF; sl->cT = tmpMeanF;
+    if (finished) {
+        EccFrameResult* r = results + frame;
+        for (int k = 0; k < 9; k++) r->warp[k] = sl->warp[k];
+        r->iters = iter; r->status = status; r->rho = rho;
+        slot_take_next(sl, queue, init_warps);
+        __threadfence();
+        atomicAdd(&queue->frames_done, 1);
+    }
+}
+
+
+}  // namespace stk

@@ -26,6 +26,7 @@
 //  blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD and
 //  its L2: the frame-0 planes they all read are fetched from HBM/MALL once per XCD.
 #include "common.h"
+#include "ecc_solve_body.h"
 
 namespace stk {
 
@@ -221,9 +222,15 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
     constexpr int P = MotionTraits<MOTION>::P;
     constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
     // XCD-aware decode: bid = xcd + 8 * (slot + n_slots * (region / 8))
-    const int bid = blockIdx.x;
+    // fused launch: the FIRST solve_n workgroups (dispatched first, so they run next to the pixel pass rather
+    // than behind it) solve the other slot group's previous pass
+    if ((int)blockIdx.x < a.solve_n) {
+        ecc_solve_body<4>(a, a.solve_slot0 + (int)blockIdx.x, a.motion, a.crit, a.queue, a.results, a.init_warps);
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.solve_n;
     const int xcd = bid & 7, q = bid >> 3;
-    const int slot = q % a.n_slots;
+    const int slot = a.slot0 + q % a.n_slots;
     const int region = (q / a.n_slots) * 8 + xcd;
     const EccSlot* sl = a.slots + slot;
     const int frame = sl->frame;
@@ -272,9 +279,15 @@ __constant__ unsigned char c_hess_ypow[36] = {0, 0, 0, 1, 1, 1, 0, 0,  0, 0, 1, 
 __global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   // 4 waves/SIMD: <= 128 VGPRs
     constexpr int MOTION = STK_MOTION_HOMOGRAPHY;
     constexpr int P = 8, NH = 36, NR = 3 * P + 6, NS = NH + NR;   // NR = 30 per-lane sums besides the Hessian
-    const int bid = blockIdx.x;
+    // fused launch: the FIRST solve_n workgroups (dispatched first, so they run next to the pixel pass rather
+    // than behind it) solve the other slot group's previous pass
+    if ((int)blockIdx.x < a.solve_n) {
+        ecc_solve_body<4>(a, a.solve_slot0 + (int)blockIdx.x, a.motion, a.crit, a.queue, a.results, a.init_warps);
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.solve_n;
     const int xcd = bid & 7, q = bid >> 3;
-    const int slot = q % a.n_slots;
+    const int slot = a.slot0 + q % a.n_slots;
     const int region = (q / a.n_slots) * 8 + xcd;
     const EccSlot* sl = a.slots + slot;
     const int frame = sl->frame;
@@ -614,8 +627,10 @@ __global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
 
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
+    // variants 0 and 3 may carry a.solve_n extra workgroups (fused solve of the other slot group)
     if (variant == 3 && motion == STK_MOTION_HOMOGRAPHY) {   // other motions: direct variant below
-        ecc_iter_h8_kernel<<<grid, 256, 0, s>>>(a);
+        if (grid + a.solve_n <= 0) return hipSuccess;
+        ecc_iter_h8_kernel<<<grid + a.solve_n, 256, 0, s>>>(a);
         return hipGetLastError();
     }
     if (variant == 2) {     // one workgroup = n_slots waves; a.nb workgroups in total (multiple of 8)
@@ -640,11 +655,13 @@ hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStr
         }
         return hipGetLastError();
     }
+    const int gridf = grid + a.solve_n;
+    if (gridf <= 0) return hipSuccess;
     switch (motion) {
-        case STK_MOTION_HOMOGRAPHY: ecc_iter_kernel<STK_MOTION_HOMOGRAPHY><<<grid, 256, 0, s>>>(a); break;
-        case STK_MOTION_AFFINE: ecc_iter_kernel<STK_MOTION_AFFINE><<<grid, 256, 0, s>>>(a); break;
-        case STK_MOTION_EUCLIDEAN: ecc_iter_kernel<STK_MOTION_EUCLIDEAN><<<grid, 256, 0, s>>>(a); break;
-        case STK_MOTION_TRANSLATION: ecc_iter_kernel<STK_MOTION_TRANSLATION><<<grid, 256, 0, s>>>(a); break;
+        case STK_MOTION_HOMOGRAPHY: ecc_iter_kernel<STK_MOTION_HOMOGRAPHY><<<gridf, 256, 0, s>>>(a); break;
+        case STK_MOTION_AFFINE: ecc_iter_kernel<STK_MOTION_AFFINE><<<gridf, 256, 0, s>>>(a); break;
+        case STK_MOTION_EUCLIDEAN: ecc_iter_kernel<STK_MOTION_EUCLIDEAN><<<gridf, 256, 0, s>>>(a); break;
+        case STK_MOTION_TRANSLATION: ecc_iter_kernel<STK_MOTION_TRANSLATION><<<gridf, 256, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -123,6 +123,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
     else if (n == "ecc_variant") { if (value < 0 || value > 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0..3"); ctx->opt_ecc_variant = (int)value; }
+    else if (n == "ecc_fused") ctx->opt_ecc_fused = value != 0;
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;
@@ -142,6 +143,7 @@ struct EccPlan {
     int ref_stride;
     size_t ref_plane_floats;
     int n_slots, nb, nsums;
+    int group_a, group_b;   // fused launches: slots [0, group_a) and [group_a, n_slots) alternate; 0/0 = not fused
 };
 
 static stk_status ecc_validate(stk_ctx* ctx, const stk_ecc_params* p, EccCriteria& crit) {
@@ -174,11 +176,23 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
         slots = (int)std::lround(4.0 * 8294400.0 / px);
         slots = std::max(4, std::min(slots, 16));
     }
-    pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
+    // Fused launches (variants 0 and 3): two groups of `slots` slots alternate, the solve of one group runs in
+    // extra workgroups of the other group's pixel pass.
+    const bool fused = (ctx->opt_ecc_variant == 0 || ctx->opt_ecc_variant == 3) && ctx->opt_ecc_fused;
+    pl.group_a = pl.group_b = 0;
+    if (fused) {
+        const int total = std::max(1, std::min(2 * slots, std::max(n_templates, 1)));
+        pl.group_a = (total + 1) / 2; pl.group_b = total / 2;
+        pl.n_slots = total;
+        slots = pl.group_a;
+    } else {
+        pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
+        slots = pl.n_slots;
+    }
     // blocks per slot: multiple of 8 (XCD-aware decode), each block = 4 waves = 4 rows per sweep
     // work units of one slot: 4-row groups (direct variant) or 64x16 tiles (tiled variant)
     const int units = ctx->opt_ecc_variant == 1 ? ((w + ECC_TILE_W - 1) / ECC_TILE_W) * ((h + ECC_TILE_H - 1) / ECC_TILE_H) : (h + 3) / 4;
-    int nb = std::max(8, std::min(units, ctx->opt_ecc_blocks / pl.n_slots));
+    int nb = std::max(8, std::min(units, ctx->opt_ecc_blocks / slots));
     if (ctx->opt_ecc_variant == 2) {
         // row-sharing variant: a workgroup = n_slots waves (one per slot) on one template row; as many
         // workgroups as keep the same number of waves in flight as the other variants
@@ -227,14 +241,18 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     a.partials = ctx->partials.as<double>();
     EccQueue* q = ctx->queue.as<EccQueue>();
     EccFrameResult* r = ctx->results.as<EccFrameResult>();
-    HIP_TRY(launch_ecc_init(a.slots, a.n_slots, q, pl.n_templates, r, init_warps_dev, ctx->stream));
+    a.slot0 = 0; a.solve_slot0 = 0; a.solve_n = 0;
+    a.motion = pl.motion; a.crit = crit; a.queue = q; a.results = r; a.init_warps = nullptr;
+    const bool fused = pl.group_a > 0;
+    long long fused_n = 0;                                  // launches issued so far (selects the group)
+    HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, q, pl.n_templates, r, init_warps_dev, ctx->stream));
     if (crit.n_iter >= 1) {
         // Enqueue chunks of (iterate, solve) launches; keep two chunks in flight and poll the
         // device-side completion counter behind each. Launches after completion are no-ops.
         const int chunk = ctx->opt_ecc_chunk;
         int inflight = 0, head = 0;
         long long launched = 0;
-        const long long max_launches = (long long)crit.n_iter * pl.n_templates + 2 * chunk;
+        const long long max_launches = 2 * ((long long)crit.n_iter * pl.n_templates + 2 * chunk) + 4;
         bool done = false;
         size_t prof_used = 0;
         if (ctx->opt_profile >= 2 && ctx->prof_ev.empty()) {
@@ -247,9 +265,17 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                 for (int c = 0; c < chunk; c++) {
                     const bool timed = ctx->opt_profile >= 2 && prof_used + 2 <= ctx->prof_ev.size();
                     if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used], ctx->stream));
+                    if (fused) {
+                        // launch n iterates group n % 2 and, in extra workgroups, solves the other group's previous pass
+                        const bool gb = (fused_n & 1) != 0;
+                        a.slot0 = gb ? pl.group_a : 0; a.n_slots = gb ? pl.group_b : pl.group_a;
+                        a.solve_slot0 = gb ? 0 : pl.group_a;
+                        a.solve_n = fused_n == 0 ? 0 : (gb ? pl.group_a : pl.group_b);
+                        fused_n++;
+                    }
                     HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->opt_ecc_variant, ctx->stream));
                     if (timed) { HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used + 1], ctx->stream)); prof_used += 2; }
-                    HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
+                    if (!fused) HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
                 }
                 launched += chunk;
                 ctx->timing.ecc_iter_launches += chunk;
