@@ -193,6 +193,11 @@ stk_status stk_warp_accumulate(stk_ctx* ctx, const stk_frames* frame /* n==1 */,
                                int32_t is_affine, int32_t border_mode, const double* border_value,
                                double alpha, int32_t accumulate, stk_image_f32* acc);
 
+/* scale_image (utils.rs:186-214) on an 8-bit grey image: aspect-preserving resize(INTER_AREA) so that the
+ * smaller dimension becomes scale_down. out must hold new_w * new_h bytes (<= width * height). */
+stk_status stk_scale_image_grey(stk_ctx* ctx, const uint8_t* grey, int32_t width, int32_t height, int32_t location,
+                                float scale_down, uint8_t* out, int32_t* new_width, int32_t* new_height);
+
 /* ORB::create_def + detect_and_compute, utils.rs:174-183. keypoints: rows of 7 floats
  * {x, y, size, angle, response, octave, class_id}; descriptors: rows of 32 bytes. */
 stk_status stk_orb_detect_and_compute(stk_ctx* ctx, const uint8_t* grey, int32_t width,

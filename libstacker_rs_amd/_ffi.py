@@ -78,6 +78,8 @@ SIGNATURES = {
                                           C.POINTER(C.c_int32)]),
     "stk_warp_accumulate": (c_status, [C.c_void_p, C.POINTER(Frames), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_double, C.c_int32, C.POINTER(ImageF32)]),
+    "stk_scale_image_grey": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stk_orb_detect_and_compute": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "stk_bf_knn2_hamming": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -365,6 +365,16 @@ class Stacker:
         self._check(st)
         return out
 
+    def scale_image_grey(self, grey, scale_down: float):
+        """utils::scale_image (utils.rs:186-214) on an 8-bit grey image: INTER_AREA, smaller dimension -> scale_down."""
+        g = np.ascontiguousarray(grey, np.uint8)
+        h, w = g.shape
+        out = np.empty(h * w, np.uint8)
+        nw, nh = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.stk_scale_image_grey(self._h, C.c_void_p(g.ctypes.data), w, h, HOST, float(scale_down),
+                                                   C.c_void_p(out.ctypes.data), C.byref(nw), C.byref(nh)))
+        return out[: nw.value * nh.value].reshape(nh.value, nw.value).copy()
+
     def orb_detect_and_compute(self, grey, max_keypoints: int = 2000):
         g = np.ascontiguousarray(grey, np.uint8)
         h, w = g.shape

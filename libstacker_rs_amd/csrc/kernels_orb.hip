@@ -49,6 +49,69 @@ hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst,
     return hipGetLastError();
 }
 
+// ---- scale_image: resize(INTER_AREA) of an 8-bit grey image (utils.rs:186-214) ---------------------------
+// One thread per destination pixel; it walks the fractional-coverage cells of its source rectangle in the
+// order of OpenCV's computeResizeAreaTab tables (partial left cell, full cells, partial right cell; rows
+// combined as sum = beta0*buf0, sum += beta_k*buf_k), so the f32 result is the same bit pattern.
+struct AreaSpan { int s1, s2; float a_first, a_full, a_last; bool has_first, has_last; };
+
+__device__ __forceinline__ AreaSpan area_span(int d, int ssize, double scale) {
+    AreaSpan sp;
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, (double)ssize - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    s2 = min(s2, ssize - 1);
+    s1 = min(s1, s2);
+    sp.s1 = s1; sp.s2 = s2;
+    sp.has_first = (s1 - f1) > 1e-3;
+    sp.a_first = (float)((s1 - f1) / cell);
+    sp.a_full = (float)(1.0 / cell);
+    sp.has_last = (f2 - s2) > 1e-3;
+    sp.a_last = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell);
+    return sp;
+}
+
+__global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __restrict__ src, int sw, int sh,
+                                                             uint8_t* __restrict__ dst, int dw, int dh, double scale_x,
+                                                             double scale_y, int isx, int isy) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    if (isx > 0) {   // integer ratios: resizeAreaFast, cvRound(sum * (1.f / area))
+        int sum = 0;
+        for (int j = 0; j < isy; j++)
+            for (int i = 0; i < isx; i++) sum += src[(size_t)(y * isy + j) * sw + x * isx + i];
+        const int r = (int)__builtin_rintf((float)sum * (1.f / (float)(isx * isy)));
+        dst[(size_t)y * dw + x] = (uint8_t)min(max(r, 0), 255);
+        return;
+    }
+    const AreaSpan sx = area_span(x, sw, scale_x), sy = area_span(y, sh, scale_y);
+    float sum = 0.f;
+    bool first_row = true;
+    auto row = [&](int yy, float beta) {
+        const uint8_t* S = src + (size_t)yy * sw;
+        float buf = 0.f;
+        if (sx.has_first) buf += (float)S[sx.s1 - 1] * sx.a_first;
+        for (int xx = sx.s1; xx < sx.s2; xx++) buf += (float)S[xx] * sx.a_full;
+        if (sx.has_last) buf += (float)S[sx.s2] * sx.a_last;
+        sum = first_row ? beta * buf : sum + beta * buf;
+        first_row = false;
+    };
+    if (sy.has_first) row(sy.s1 - 1, sy.a_first);
+    for (int yy = sy.s1; yy < sy.s2; yy++) row(yy, sy.a_full);
+    if (sy.has_last) row(sy.s2, sy.a_last);
+    const int r = (int)__builtin_rintf(sum);
+    dst[(size_t)y * dw + x] = (uint8_t)min(max(r, 0), 255);
+}
+
+hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s) {
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+    const int ix = (int)std::lrint(scale_x), iy = (int)std::lrint(scale_y);
+    const bool fast = std::fabs(scale_x - ix) < 2.220446049250313e-16 && std::fabs(scale_y - iy) < 2.220446049250313e-16;
+    resize_area_u8_kernel<<<grid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, scale_x, scale_y, fast ? ix : 0, fast ? iy : 0);
+    return hipGetLastError();
+}
+
 // ---- FAST -----------------------------------------------------------------------------------------
 __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int stride, int thr) {
     const int v = p[0];

@@ -22,7 +22,7 @@ using namespace stk;
 namespace stk {
 
 struct KeypointWorkspace {
-    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn;
+    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn, gfull;
     bool pattern_uploaded = false;
     OrbSelected* host_sel = nullptr;        // pinned
     OrbLevelState* host_states = nullptr;   // pinned
@@ -33,7 +33,7 @@ struct KeypointWorkspace {
 KeypointWorkspace* keypoint_workspace_create() { return new KeypointWorkspace(); }
 void keypoint_workspace_destroy(KeypointWorkspace* k) {
     if (!k) return;
-    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn})
+    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn, &k->gfull})
         b->release();
     if (k->host_sel) (void)hipHostFree(k->host_sel);
     if (k->host_states) (void)hipHostFree(k->host_states);
@@ -247,6 +247,29 @@ stk_status stk_orb_detect_and_compute(stk_ctx* ctx, const uint8_t* grey, int32_t
     return STK_OK;
 }
 
+stk_status stk_scale_image_grey(stk_ctx* ctx, const uint8_t* grey, int32_t width, int32_t height, int32_t location,
+                                float scale_down, uint8_t* out, int32_t* new_width, int32_t* new_height) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!grey || !out || width <= 0 || height <= 0 || !new_width || !new_height) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
+    int nw, nh;
+    if (!(scale_down > 0) || !scaled_size(width, height, scale_down, nw, nh))
+        return fail(ctx, STK_BACKEND_ERROR, "resize(INTER_AREA): scale_down must give a non-empty image no larger than the input");
+    (void)hipSetDevice(ctx->device);
+    KeypointWorkspace* ws = ctx->kp;
+    const size_t ib = (size_t)width * height, ob = (size_t)nw * nh;
+    const uint8_t* src = grey; uint8_t* dst = out;
+    if (location == STK_HOST) {
+        HIP_TRY(ws->gfull.reserve(ib)); HIP_TRY(ws->score.reserve(ob));
+        HIP_TRY(hipMemcpyAsync(ws->gfull.p, grey, ib, hipMemcpyHostToDevice, ctx->stream));
+        src = ws->gfull.as<uint8_t>(); dst = ws->score.as<uint8_t>();
+    }
+    HIP_TRY(launch_resize_area_u8(src, width, height, dst, nw, nh, ctx->stream));
+    if (location == STK_HOST) HIP_TRY(hipMemcpyAsync(out, dst, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *new_width = nw; *new_height = nh;
+    return STK_OK;
+}
+
 stk_status stk_bf_knn2_hamming(stk_ctx* ctx, const uint8_t* query, int32_t n_query, const uint8_t* train, int32_t n_train,
                                int32_t* out) {
     if (!ctx) return STK_INVALID_PARAMS;
@@ -286,7 +309,6 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     (void)hipSetDevice(ctx->device);
     if (frames->depth != 8)   // ORB::detectAndCompute asserts an 8-bit image
         return fail(ctx, STK_BACKEND_ERROR, "ORB: only 8-bit images are supported");
-    if (scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "keypoint_match with scale_down_width (lib.rs:355) is not implemented yet");
     if (params->method != STK_METHOD_RANSAC && params->method != STK_METHOD_LEAST_SQUARES) {
         if (params->method == STK_METHOD_LMEDS || params->method == STK_METHOD_RHO)
             return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: LMEDS / RHO are not implemented");
@@ -296,6 +318,15 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
         return fail(ctx, params->border_mode == STK_BORDER_TRANSPARENT ? STK_NOT_IMPLEMENTED : STK_BACKEND_ERROR, "unsupported border mode");
     const int w = frames->width, h = frames->height, n = frames->n;
     if (w >= 65536 || h >= 32768) return fail(ctx, STK_INVALID_PARAMS, "image too large for ORB");
+    // keypoint_match_scale_down (lib.rs:355-601): ORB and the homography on INTER_AREA-shrunk greys
+    const bool scaled = scale_down_width > 0;
+    int ew = w, eh = h;
+    if (scaled) {
+        if (scale_down_width >= (float)w)   // lib.rs:377-382
+            return fail(ctx, STK_INVALID_PARAMS, "scale_down_to was larger (or equal) to the full image width: full_size:" +
+                                                  std::to_string(w) + ", scale_down_to:" + std::to_string(scale_down_width));
+        if (!scaled_size(w, h, scale_down_width, ew, eh)) return fail(ctx, STK_INVALID_PARAMS, "scale_down_width gives an empty image");
+    }
     if ((st = image_check(ctx, sum, w, h, 3))) return st;
     if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
     timing_begin(ctx);
@@ -304,8 +335,17 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     if ((st = resolve_frames(ctx, frames, dev))) return st;
     const size_t rb = frame_row_bytes(frames);
     OrbGeometry g;
-    if ((st = orb_prepare(ctx, w, h, g))) return st;
+    if ((st = orb_prepare(ctx, ew, eh, g))) return st;
     KeypointWorkspace* ws = ctx->kp;
+    if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
+    // grey of frame i into level 0 of the ORB pyramid, through scale_image when scaling (utils.rs:186-214)
+    auto grey_level0 = [&](const void* frame) -> stk_status {
+        if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->pyr.p, ctx->stream)); return STK_OK; }
+        HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->gfull.p, ctx->stream));
+        HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, ws->pyr.as<uint8_t>(), ew, eh, ctx->stream));
+        return STK_OK;
+    };
+    const double fix_sx = (double)w / (double)ew, fix_sy = (double)h / (double)eh;   // adjust_homography_for_scale_f64
     HIP_TRY(ws->desc0.reserve(MAX_KP * 32));
     HIP_TRY(ws->desc.reserve(MAX_KP * 32));
     HIP_TRY(ws->knn.reserve(MAX_KP * 16));
@@ -318,7 +358,7 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
 
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     // reference frame: grey -> ORB, descriptors stay in desc0 (lib.rs:161-175)
-    HIP_TRY(launch_grey(dev[0], 8, w, h, rb, ws->pyr.p, ctx->stream));
+    if ((st = grey_level0(dev[0]))) return st;
     std::vector<HostKeypoint> kp0;
     if ((st = orb_run(ctx, g, ws->desc0.as<uint8_t>(), MAX_KP, kp0))) return st;
     const int n0 = (int)kp0.size();
@@ -332,7 +372,7 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     std::vector<HostKeypoint> kp;
     std::vector<Match> ms;
     for (int i = 1; i < n; i++) {
-        HIP_TRY(launch_grey(dev[i], 8, w, h, rb, ws->pyr.p, ctx->stream));
+        if ((st = grey_level0(dev[i]))) return st;
         if ((st = orb_run(ctx, g, ws->desc.as<uint8_t>(), MAX_KP, kp))) return st;
         const int nk = (int)kp.size();
         bool ok = true;
@@ -368,7 +408,8 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
             if (rc != 0 || !found) ok = false;                                       // Err(_) | empty -> skip  lib.rs:275-282
             else {
                 const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
-                if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284
+                if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284 / 521 (on the small-image H)
+                else if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
                 for (uint8_t m : mask) n_inl += m;
             }
         }

@@ -23,6 +23,13 @@ KeypointWorkspace* keypoint_workspace_create();
 void keypoint_workspace_destroy(KeypointWorkspace*);
 
 hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s);
+hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s);
+// scale_image's target size (utils.rs:186-214): the SMALLER dimension becomes scale_down, `as i32` truncation
+inline bool scaled_size(int w, int h, float scale_down, int& nw, int& nh) {
+    const double sf = w < h ? (double)scale_down / (double)w : (double)scale_down / (double)h;
+    nw = (int)((double)w * sf); nh = (int)((double)h * sf);
+    return nw > 0 && nh > 0 && nw <= w && nh <= h;
+}
 hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
                              OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,
                              const OrbUmax& um, hipStream_t s);

@@ -368,8 +368,19 @@ stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk
     if ((st = ecc_validate(ctx, params, crit))) return st;
     if (frames->depth == 16)  // findTransformECC accepts CV_8UC1 / CV_32FC1 only
         return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: 16-bit images are not supported (8UC1 or 32FC1 only)");
-    if (scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "ecc_match with scale_down_width (lib.rs:849) is not implemented yet");
     const int w = frames->width, h = frames->height, n = frames->n;
+    // ecc_match_scaling_down (lib.rs:849-1028): ECC on INTER_AREA-shrunk greys, then the warp is rescaled
+    const bool scaled = scale_down_width > 0;
+    int ew = w, eh = h;
+    if (scaled) {
+        if (scale_down_width >= (float)w)   // lib.rs:876-881
+            return fail(ctx, STK_INVALID_PARAMS, "scale_down_to was larger (or equal) to the full image width: full_size:" +
+                                                  std::to_string(w) + ", scale_down_to:" + std::to_string(scale_down_width));
+        if (scale_down_width <= 10.0f)      // lib.rs:883-888
+            return fail(ctx, STK_INVALID_PARAMS, "scale_down_to was too small scale_down_to:" + std::to_string(scale_down_width));
+        if (frames->depth != 8) return fail(ctx, STK_NOT_IMPLEMENTED, "ecc_match with scale_down_width: only 8-bit frames");
+        if (!scaled_size(w, h, scale_down_width, ew, eh)) return fail(ctx, STK_INVALID_PARAMS, "scale_down_width gives an empty image");
+    }
     if ((st = image_check(ctx, sum, w, h, 3))) return st;
     if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
     timing_begin(ctx);
@@ -378,13 +389,27 @@ stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk
     if ((st = resolve_frames(ctx, frames, dev))) return st;
     const size_t rb = frame_row_bytes(frames);
     EccPlan pl{};
-    if ((st = ecc_plan(ctx, w, h, n - 1, params->motion_type, pl))) return st;
+    if ((st = ecc_plan(ctx, ew, eh, n - 1, params->motion_type, pl))) return st;
 
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    if ((st = ecc_prepare_reference(ctx, pl, dev[0], frames->depth, 3, rb, params->gauss_filt_size))) return st;
-    for (int i = 1; i < n; i++)
-        HIP_TRY(launch_grey_blur(dev[i], frames->depth, 3, w, h, rb, params->gauss_filt_size,
-                                 ctx->templates.as<float>() + pl.templ_plane_stride * (i - 1), pl.templ_row_stride, ctx->stream));
+    if (!scaled) {
+        if ((st = ecc_prepare_reference(ctx, pl, dev[0], frames->depth, 3, rb, params->gauss_filt_size))) return st;
+        for (int i = 1; i < n; i++)
+            HIP_TRY(launch_grey_blur(dev[i], frames->depth, 3, w, h, rb, params->gauss_filt_size,
+                                     ctx->templates.as<float>() + pl.templ_plane_stride * (i - 1), pl.templ_row_stride, ctx->stream));
+    } else {
+        // grey (full size) -> scale_image (INTER_AREA) -> blur on the small grey
+        HIP_TRY(ctx->scratch.reserve((size_t)w * h + (size_t)ew * eh + 256));
+        uint8_t* gfull = ctx->scratch.as<uint8_t>();
+        uint8_t* gsmall = gfull + (((size_t)w * h + 255) & ~(size_t)255);
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(launch_grey(dev[i], 8, w, h, rb, gfull, ctx->stream));
+            HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, ctx->stream));
+            if (i == 0) { if ((st = ecc_prepare_reference(ctx, pl, gsmall, 8, 1, (size_t)ew, params->gauss_filt_size))) return st; }
+            else HIP_TRY(launch_grey_blur(gsmall, 8, 1, ew, eh, (size_t)ew, params->gauss_filt_size,
+                                          ctx->templates.as<float>() + pl.templ_plane_stride * (i - 1), pl.templ_row_stride, ctx->stream));
+        }
+    }
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     std::vector<EccFrameResult> res;
     if ((st = ecc_run(ctx, pl, crit, nullptr, res))) return st;
@@ -398,7 +423,16 @@ stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk
         stats[0].rho = 1;
     }
     for (int i = 1; i < n; i++) {
-        const EccFrameResult& e = res[i - 1];
+        EccFrameResult& e = res[i - 1];
+        if (scaled && !e.status) {
+            if (is_affine) {                               // lib.rs:941-951: only the translation column
+                e.warp[2] *= (float)w / (float)ew;
+                e.warp[5] *= (float)h / (float)eh;
+            } else {                                       // adjust_homography_for_scale_f32, utils.rs:229-239
+                const double sx = (double)w / (double)ew, sy = (double)h / (double)eh;
+                e.warp[2] *= (float)sx; e.warp[5] *= (float)sy; e.warp[6] /= (float)sx; e.warp[7] /= (float)sy;
+            }
+        }
         if (stats) {
             stats[i].status = e.status ? 2 : 0; stats[i].iterations = e.iters; stats[i].rho = e.rho;
             for (int k = 0; k < 9; k++) stats[i].warp[k] = e.warp[k];

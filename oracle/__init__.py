@@ -128,7 +128,7 @@ def find_transform_ecc(templ: np.ndarray, inp: np.ndarray, warp: np.ndarray, mot
 
 
 def ecc_match(frames, motion=MOTION_HOMOGRAPHY, max_count=5000, epsilon=1e-5, gauss_filt_size=5,
-              n_threads=0):
+              n_threads=0, scale_down_width=None):
     """ecc_match_no_scaling (lib.rs:719-847) on decoded BGR frames. Returns (image, warps, iters)."""
     frames = [np.ascontiguousarray(f) for f in frames]
     n = len(frames)
@@ -139,7 +139,8 @@ def ecc_match(frames, motion=MOTION_HOMOGRAPHY, max_count=5000, epsilon=1e-5, ga
     iters = np.zeros(n, np.int32)
     rc = lib().orc_ecc_match(ptrs, n, w, h, _depth(frames[0]), int(motion), int(max_count is not None),
                              int(max_count or 0), int(epsilon is not None), C.c_double(epsilon or 0.0),
-                             int(gauss_filt_size), _p(out), _p(warps), _p(iters), int(n_threads))
+                             int(gauss_filt_size), C.c_float(scale_down_width or 0.0), _p(out), _p(warps), _p(iters),
+                             int(n_threads))
     if rc:
         raise RuntimeError("orc_ecc_match rc=%d" % rc)
     return out, warps, iters
@@ -216,7 +217,7 @@ def find_homography(src_pts, dst_pts, method: int = 8, ransac_reproj_threshold: 
 
 def keypoint_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0, match_keep_ratio: float = 0.80,
                    match_ratio: float = 0.9, border_mode: int = BORDER_CONSTANT, border_value=(0, 0, 0, 0),
-                   n_threads: int = 0, details: bool = False):
+                   n_threads: int = 0, details: bool = False, scale_down_width=None):
     """keypoint_match_no_scale (lib.rs:146-353) with the documented drop semantics -> (dropped, image)."""
     frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
     n = len(frames)
@@ -229,7 +230,23 @@ def keypoint_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0
     dropped = C.c_int(0)
     rc = lib().orc_keypoint_match(ptrs, n, w, h, int(method), C.c_double(ransac_reproj_threshold),
                                   C.c_float(match_keep_ratio), C.c_float(match_ratio), int(border_mode), _p(bv),
-                                  _p(out), C.byref(dropped), _p(Hs), _p(status), int(n_threads))
+                                  C.c_float(scale_down_width or 0.0), _p(out), C.byref(dropped), _p(Hs), _p(status),
+                                  int(n_threads))
     if rc:
         raise RuntimeError("orc_keypoint_match rc=%d" % rc)
     return (dropped.value, out, Hs, status) if details else (dropped.value, out)
+
+
+def scaled_size(w: int, h: int, scale_down: float):
+    nw, nh = C.c_int(0), C.c_int(0)
+    lib().orc_scaled_size(w, h, C.c_float(scale_down), C.byref(nw), C.byref(nh))
+    return nw.value, nh.value
+
+
+def resize_area_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    s = np.ascontiguousarray(src, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    rc = lib().orc_resize_area_u8(_p(s), s.shape[1], s.shape[0], _p(out), dw, dh)
+    if rc:
+        raise ValueError("orc_resize_area_u8 rc=%d" % rc)
+    return out

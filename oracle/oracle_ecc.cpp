@@ -16,6 +16,8 @@ int orc_warp_frame(const void* src, int depth, int w, int h, int cn, size_t stri
                    const double* M, int is_affine, int border_mode, const double* border_value,
                    double alpha, int subpixel_bits, float* dst, int accumulate);
 int orc_scale(const float* in, size_t n, double divisor, float* out);
+int orc_scaled_size(int w, int h, float scale_down, int* nw, int* nh);
+int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
 }
 
 namespace {
@@ -351,18 +353,29 @@ int orc_find_transform_ecc(const void* templ, int tw, int th, const void* input,
 // ecc_match_no_scaling, lib.rs:719-847. frames: n pointers to BGR u8 images (w*h*3, tight).
 // Frame-parallel with one private accumulator per thread and a final pairwise sum, mirroring
 // the Rayon try_fold/try_reduce. warps_out (optional): n*9 floats. Returns 0 or 10+ecc error.
+// scale_down > 0 selects ecc_match_scaling_down (lib.rs:849-1028): ECC on INTER_AREA-shrunk greys, then
+// the translation rescale (affine family, lib.rs:941-951) or adjust_homography_for_scale_f32 (utils.rs:218-248).
 int orc_ecc_match(const void* const* frames, int n, int w, int h, int depth, int motion, int has_count,
-                  int max_count, int has_eps, double eps, int gauss, float* out, float* warps_out,
+                  int max_count, int has_eps, double eps, int gauss, float scale_down, float* out, float* warps_out,
                   int* iters_out, int n_threads) {
-    if (n <= 0) return 1;                               // NotEnoughFiles lib.rs:725
+    if (n <= 0) return 1;                               // NotEnoughFiles lib.rs:725, 859
     if (!has_count && !has_eps) return 4;
+    int ew = w, eh = h;                                 // size the ECC runs at
+    if (scale_down > 0) {
+        if (scale_down >= (float)w) return 2;           // InvalidParams lib.rs:876-881
+        if (scale_down <= 10.0f) return 2;              // InvalidParams lib.rs:883-888
+        if (depth != 8) return 4;
+        if (orc_scaled_size(w, h, scale_down, &ew, &eh)) return 2;
+    }
     const size_t npx = (size_t)w * h, nel = npx * 3;
     const size_t gsz = depth / 8;
     std::vector<uint8_t> grey0(npx * gsz);
     orc_grey(frames[0], depth, w, h, 0, grey0.data());
     // findTransformECC accepts 8UC1 / 32FC1 only: 16-bit input fails in the reference.
     if (depth == 16) return 4;
-    orc_ecc_input* in = orc_ecc_prepare_input(grey0.data(), depth, w, h, gauss);
+    std::vector<uint8_t> small0;
+    if (scale_down > 0) { small0.resize((size_t)ew * eh); orc_resize_area_u8(grey0.data(), w, h, small0.data(), ew, eh); }
+    orc_ecc_input* in = orc_ecc_prepare_input(scale_down > 0 ? small0.data() : grey0.data(), depth, ew, eh, gauss);
     if (!in) return 4;
 #ifdef _OPENMP
     const int T = n_threads > 0 ? n_threads : omp_get_max_threads();
@@ -389,15 +402,25 @@ int orc_ecc_match(const void* const* frames, int n, int w, int h, int depth, int
         if (i > 0) {
             std::vector<uint8_t> grey(npx * gsz);
             orc_grey(frames[i], depth, w, h, 0, grey.data());
-            std::vector<float> tf(npx);
-            orc_gaussian_blur_f32(grey.data(), depth, w, h, gauss, tf.data());
+            std::vector<float> tf((size_t)ew * eh);
+            if (scale_down > 0) {
+                std::vector<uint8_t> sm((size_t)ew * eh);
+                orc_resize_area_u8(grey.data(), w, h, sm.data(), ew, eh);
+                orc_gaussian_blur_f32(sm.data(), 8, ew, eh, gauss, tf.data());
+            } else orc_gaussian_blur_f32(grey.data(), depth, w, h, gauss, tf.data());
             double rho;
-            int rc;
-            {
-                // inner loops are OpenMP-parallel too; nested regions stay serial by default
-                rc = orc_ecc_run(tf.data(), w, h, in, wm, motion, has_count, max_count, has_eps, eps, &rho, &its);
-            }
+            // inner loops are OpenMP-parallel too; nested regions stay serial by default
+            const int rc = orc_ecc_run(tf.data(), ew, eh, in, wm, motion, has_count, max_count, has_eps, eps, &rho, &its);
             if (rc) { err = 10 + rc; continue; }
+            if (scale_down > 0) {
+                if (motion != MOTION_HOMOGRAPHY) {          // lib.rs:941-951: only the translation column is rescaled
+                    wm[2] *= (float)w / (float)ew;
+                    wm[5] *= (float)h / (float)eh;
+                } else {                                    // utils.rs:229-239 with $type = f32
+                    const double sx = (double)w / (double)ew, sy = (double)h / (double)eh;
+                    wm[2] *= (float)sx; wm[5] *= (float)sy; wm[6] /= (float)sx; wm[7] /= (float)sy;
+                }
+            }
         }
         double Md[9]; for (int k = 0; k < 9; k++) Md[k] = wm[k];
         if (i == 0) orc_warp_frame(frames[0], depth, w, h, 3, 0, I3, 1, BORDER_CONSTANT, nullptr, alpha, 0, acc.data(), !fresh ? 1 : 0);

@@ -244,3 +244,75 @@ int orc_scale(const float* in, size_t n, double divisor, float* out) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// scale_image (utils.rs:186-214): aspect-preserving resize(INTER_AREA) so that the SMALLER
+// dimension becomes `scale_down` (despite the "width" in the caller's parameter name).
+// ---------------------------------------------------------------------------------------
+extern "C" int orc_scaled_size(int w, int h, float scale_down, int* nw, int* nh) {
+    const double sf = w < h ? (double)scale_down / (double)w : (double)scale_down / (double)h;
+    *nw = (int)((double)w * sf);        // `as i32`: truncation
+    *nh = (int)((double)h * sf);
+    return (*nw > 0 && *nh > 0) ? 0 : 3;
+}
+
+namespace {
+struct DecimateAlpha { int si, di; float alpha; };
+// imgproc/src/resize.cpp computeResizeAreaTab [OCV-RECALL]
+int area_tab(int ssize, int dsize, double scale, std::vector<DecimateAlpha>& tab) {
+    tab.clear();
+    for (int dx = 0; dx < dsize; dx++) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cellWidth = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) tab.push_back({sx1 - 1, dx, (float)((sx1 - fsx1) / cellWidth)});
+        for (int sx = sx1; sx < sx2; sx++) tab.push_back({sx, dx, (float)(1.0 / cellWidth)});
+        if (fsx2 - sx2 > 1e-3) tab.push_back({sx2, dx, (float)(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth)});
+    }
+    return (int)tab.size();
+}
+}  // namespace
+
+// resize(src, dsize, INTER_AREA) for an 8-bit single-channel image, shrinking in both directions.
+// Integer ratios take resizeAreaFast (sum * (1.f/area), cvRound); otherwise the fractional-coverage
+// tables, f32 accumulation in table order, rows combined as sum = beta0*buf0; sum += beta_k*buf_k.
+extern "C" int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+    if (dw <= 0 || dh <= 0 || dw > sw || dh > sh) return 3;
+    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+    const int isx = sat_int(scale_x), isy = sat_int(scale_y);
+    if (std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON) {
+        const float sc = 1.f / (isx * isy);
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++) {
+                int sum = 0;
+                for (int j = 0; j < isy; j++) for (int i = 0; i < isx; i++) sum += src[(size_t)(y * isy + j) * sw + x * isx + i];
+                dst[(size_t)y * dw + x] = (uint8_t)std::min(std::max(cv_round((float)sum * sc), 0), 255);
+            }
+        return 0;
+    }
+    std::vector<DecimateAlpha> xt, yt;
+    area_tab(sw, dw, scale_x, xt);
+    area_tab(sh, dh, scale_y, yt);
+    std::vector<float> buf(dw), sum(dw);
+    int prev_dy = yt.empty() ? 0 : yt[0].di;
+    std::fill(sum.begin(), sum.end(), 0.f);
+    for (size_t j = 0; j < yt.size(); j++) {
+        const float beta = yt[j].alpha;
+        const int dy = yt[j].di, sy = yt[j].si;
+        const uint8_t* S = src + (size_t)sy * sw;
+        std::fill(buf.begin(), buf.end(), 0.f);
+        for (const DecimateAlpha& t : xt) buf[t.di] += S[t.si] * t.alpha;
+        if (dy != prev_dy) {
+            uint8_t* D = dst + (size_t)prev_dy * dw;
+            for (int dx = 0; dx < dw; dx++) { D[dx] = (uint8_t)std::min(std::max(cv_round(sum[dx]), 0), 255); sum[dx] = beta * buf[dx]; }
+            prev_dy = dy;
+        } else {
+            for (int dx = 0; dx < dw; dx++) sum[dx] += beta * buf[dx];
+        }
+    }
+    uint8_t* D = dst + (size_t)prev_dy * dw;
+    for (int dx = 0; dx < dw; dx++) D[dx] = (uint8_t)std::min(std::max(cv_round(sum[dx]), 0), 255);
+    return 0;
+}

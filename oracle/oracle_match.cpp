@@ -17,6 +17,8 @@ int orc_warp_frame(const void* src, int depth, int w, int h, int cn, size_t stri
                    int is_affine, int border_mode, const double* border_value, double alpha, int subpixel_bits,
                    float* dst, int accumulate);
 int orc_scale(const float* in, size_t n, double divisor, float* out);
+int orc_scaled_size(int w, int h, float scale_down, int* nw, int* nh);
+int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
 int orc_orb_detect_and_compute(const uint8_t* grey, int w, int h, int max_keypoints, float* kp_out,
                                uint8_t* desc_out, int* n_out);
 }
@@ -370,18 +372,26 @@ int orc_find_homography(const float* src_pts, const float* dst_pts, int n, int m
 // keypoint_match_no_scale, lib.rs:146-353, with the DOCUMENTED drop semantics (lib.rs:98): a frame
 // whose homography cannot be estimated is skipped and counted; divisor n - dropped.
 // Returns 0 ok, 1 NotEnoughFiles, 2 all frames dropped (InvalidParams, lib.rs:324), 4 backend error.
+// scale_down > 0 selects keypoint_match_scale_down (lib.rs:355-601): ORB on INTER_AREA-shrunk greys, homography
+// estimated there, then adjust_homography_for_scale_f64 (utils.rs:218-248) before the full-size warp.
 int orc_keypoint_match(const void* const* frames, int n, int w, int h, int method, double thr, float keep_ratio,
-                       float match_ratio, int border_mode, const double* border_value, float* out, int* dropped_out,
-                       double* H_out, int* status_out, int n_threads) {
+                       float match_ratio, int border_mode, const double* border_value, float scale_down, float* out,
+                       int* dropped_out, double* H_out, int* status_out, int n_threads) {
     if (n <= 0) return 1;
     const size_t npx = (size_t)w * h, nel = npx * 3;
+    int ew = w, eh = h;
+    if (scale_down > 0) {
+        if (scale_down >= (float)w) return 3;               // InvalidParams lib.rs:377-382
+        if (orc_scaled_size(w, h, scale_down, &ew, &eh)) return 3;
+    }
     std::vector<uint8_t> g0(npx);
     orc_grey(frames[0], 8, w, h, 0, g0.data());
+    if (scale_down > 0) { std::vector<uint8_t> sm((size_t)ew * eh); orc_resize_area_u8(g0.data(), w, h, sm.data(), ew, eh); g0.swap(sm); }
     const int MAXKP = 4096;
     std::vector<float> kp0((size_t)MAXKP * 7);
     std::vector<uint8_t> de0((size_t)MAXKP * 32);
     int n0 = 0;
-    orc_orb_detect_and_compute(g0.data(), w, h, MAXKP, kp0.data(), de0.data(), &n0);
+    orc_orb_detect_and_compute(g0.data(), ew, eh, MAXKP, kp0.data(), de0.data(), &n0);
 #ifdef _OPENMP
     const int T = n_threads > 0 ? n_threads : omp_get_max_threads();
 #else
@@ -402,10 +412,11 @@ int orc_keypoint_match(const void* const* frames, int n, int w, int h, int metho
         if (i > 0) {
             std::vector<uint8_t> g(npx);
             orc_grey(frames[i], 8, w, h, 0, g.data());
+            if (scale_down > 0) { std::vector<uint8_t> sm((size_t)ew * eh); orc_resize_area_u8(g.data(), w, h, sm.data(), ew, eh); g.swap(sm); }
             std::vector<float> kp((size_t)MAXKP * 7);
             std::vector<uint8_t> de((size_t)MAXKP * 32);
             int nk = 0;
-            orc_orb_detect_and_compute(g.data(), w, h, MAXKP, kp.data(), de.data(), &nk);
+            orc_orb_detect_and_compute(g.data(), ew, eh, MAXKP, kp.data(), de.data(), &nk);
             // query = frame-0 descriptors, train = frame-i descriptors (lib.rs:208-219)
             std::vector<int> knn((size_t)std::max(n0, 1) * 4);
             orc_bf_knn2_hamming(de0.data(), n0, de.data(), nk, knn.data());
@@ -434,6 +445,10 @@ int orc_keypoint_match(const void* const* frames, int n, int w, int h, int metho
                 else {
                     const double det = Hm[0] * (Hm[4] * Hm[8] - Hm[5] * Hm[7]) - Hm[1] * (Hm[3] * Hm[8] - Hm[5] * Hm[6]) + Hm[2] * (Hm[3] * Hm[7] - Hm[4] * Hm[6]);
                     if (std::fabs(det) < 1e-6) status = 1;
+                    else if (scale_down > 0) {              // adjust_homography_for_scale_f64, utils.rs:229-239
+                        const double sx = (double)w / (double)ew, sy = (double)h / (double)eh;
+                        Hm[2] *= sx; Hm[5] *= sy; Hm[6] /= sx; Hm[7] /= sy;
+                    }
                 }
             }
         }

@@ -158,3 +158,24 @@ def test_slot_count_does_not_change_results(stacker, small_stack):
             stacker.set_option("ecc_slots", 0)
         assert np.array_equal(out, base)
         assert [s["iterations"] for s in s1] == [s["iterations"] for s in s0]
+
+
+def test_ecc_match_scaling_down_matches_oracle(stacker):
+    frames, G = synth.make_stack(3, 640, 480)
+    frames = frames.numpy()
+    for motion, omotion in ((MotionType.Homography, oracle.MOTION_HOMOGRAPHY), (MotionType.Affine, oracle.MOTION_AFFINE)):
+        p = EccMatchParameters(motion, 5000, 1e-5, 5)
+        out, stats = stacker.ecc_match(list(frames), p, scale_down_width=240.0, return_stats=True)
+        ref, warps, iters = oracle.ecc_match(list(frames), motion=omotion, scale_down_width=240.0)
+        for i in (1, 2):
+            assert synth.corner_error(stats[i]["warp"], warps[i], 640, 480) <= 0.1      # 0.05 px at half size
+            assert abs(stats[i]["iterations"] - int(iters[i])) <= 1
+        rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+        assert np.percentile(rel[4:-4, 4:-4], 99.5) < 4e-3
+    for i in (1, 2):                                             # full-size truth (homography run)
+        assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 4.0 or motion != MotionType.Homography
+    from libstacker_rs_amd import InvalidParams
+    with pytest.raises(InvalidParams):
+        stacker.ecc_match(list(frames), PARAMS, scale_down_width=640.0)     # lib.rs:876
+    with pytest.raises(InvalidParams):
+        stacker.ecc_match(list(frames), PARAMS, scale_down_width=10.0)      # lib.rs:883

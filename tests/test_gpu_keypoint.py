@@ -138,8 +138,8 @@ def test_keypoint_match_errors(stacker, kp_stack):
         stacker.keypoint_match([], PARAMS)
     with pytest.raises(OpenCvError):
         stacker.keypoint_match([f.astype(np.uint16) for f in frames[:2]], PARAMS)      # ORB needs 8-bit
-    with pytest.raises(NotImplementedYet):
-        stacker.keypoint_match(list(frames[:2]), PARAMS, scale_down_width=400.0)
+    with pytest.raises(InvalidParams):
+        stacker.keypoint_match(list(frames[:2]), PARAMS, scale_down_width=640.0)        # >= full width, lib.rs:377
     with pytest.raises(InvalidParams):
         stacker.keypoint_match([frames[0], frames[1][:100]], PARAMS)                   # mismatched sizes
 
@@ -153,4 +153,28 @@ def test_keypoint_match_border_mode_and_value(stacker, kp_stack):
     p = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9, oracle.BORDER_CONSTANT, (0.5, 0.25, 1.0, 0))
     _, out = stacker.keypoint_match(list(frames[:3]), p)
     _, ref = oracle.keypoint_match(list(frames[:3]), border_value=(0.5, 0.25, 1.0, 0))
+    assert np.max(np.abs(out - ref)) <= 4e-6
+
+
+def test_scale_image_inter_area_bit_exact(stacker):
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    for sd in (200.0, 240.0, 333.0, 97.5):                  # 240 -> exact 2x (resizeAreaFast), others fractional
+        nw, nh = oracle.scaled_size(640, 480, sd)
+        got = stacker.scale_image_grey(g, sd)
+        assert got.shape == (nh, nw)
+        assert np.array_equal(got, oracle.resize_area_u8(g, nw, nh))
+    tall = rng.integers(0, 256, (300, 120), dtype=np.uint8)   # width < height: the WIDTH becomes scale_down
+    got = stacker.scale_image_grey(tall, 60.0)
+    assert got.shape == (150, 60) and np.array_equal(got, oracle.resize_area_u8(tall, 60, 150))
+
+
+def test_keypoint_match_scale_down_matches_oracle(stacker, kp_stack):
+    frames, G = kp_stack
+    dropped, out, stats = stacker.keypoint_match(list(frames), PARAMS, scale_down_width=300.0, return_stats=True)
+    d_o, ref, Hs, status = oracle.keypoint_match(list(frames), details=True, scale_down_width=300.0)
+    assert dropped == d_o == 0
+    for i in range(1, len(frames)):
+        assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-9)         # incl. the 4-entry rescale (utils.rs:236-239)
+        assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 2.5    # coarser: features found at 0.62x
     assert np.max(np.abs(out - ref)) <= 4e-6
