@@ -176,11 +176,12 @@ def main() -> None:
             traffic = None
             if args.workload == "ecc_4k" and world == 1 and not args.opt and not args.ecc_slots:
                 try:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))["stk::ecc_iter_kernel<3>"]
+                    allk = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
+                    pm = next(v for k, v in allk.items() if k.startswith("stk::ecc_iter_h8_kernel"))
                     traffic = round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1)
                 except Exception:
                     traffic = None
-            res["roofline"] = {"kernel": "ecc_iter_kernel<HOMOGRAPHY>", "bound": "hbm", "achieved": round(achieved, 1),
+            res["roofline"] = {"kernel": "ecc_iter_h8_kernel (ECC iteration pass, homography)", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "traffic_source": "rocprofv3 --pmc (profiles/r01/pmc_summary.json)" if traffic else None,
                                "avg_launch_ms": round(avg_ms, 5), "launches": launches,

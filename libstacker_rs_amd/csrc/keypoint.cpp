@@ -295,7 +295,7 @@ stk_status stk_find_homography(stk_ctx* ctx, const float* src_pts, const float* 
     int f = 0;
     const int rc = geom::find_homography(src_pts, dst_pts, n, method, thr, H, inlier_mask, &f);
     *found = f;
-    if (rc == 7) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: LMEDS / RHO are not implemented");
+    if (rc == 7) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: RHO is not implemented");
     if (rc != 0) return fail(ctx, STK_BACKEND_ERROR, "findHomography: needs at least 4 point pairs and a known method");
     return STK_OK;
 }
@@ -309,9 +309,9 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     (void)hipSetDevice(ctx->device);
     if (frames->depth != 8)   // ORB::detectAndCompute asserts an 8-bit image
         return fail(ctx, STK_BACKEND_ERROR, "ORB: only 8-bit images are supported");
-    if (params->method != STK_METHOD_RANSAC && params->method != STK_METHOD_LEAST_SQUARES) {
-        if (params->method == STK_METHOD_LMEDS || params->method == STK_METHOD_RHO)
-            return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: LMEDS / RHO are not implemented");
+    if (params->method != STK_METHOD_RANSAC && params->method != STK_METHOD_LEAST_SQUARES && params->method != STK_METHOD_LMEDS) {
+        if (params->method == STK_METHOD_RHO)
+            return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: RHO is not implemented");
         return fail(ctx, STK_BACKEND_ERROR, "findHomography: unknown estimation method");
     }
     if (params->border_mode < 0 || params->border_mode > 4)

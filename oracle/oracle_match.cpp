@@ -192,6 +192,17 @@ int find_inliers(const P2* M, const P2* m, int count, const double* H, double th
     return nz;
 }
 
+// HomographyEstimatorCallback::computeError: squared reprojection error in f32
+void reproj_errors(const P2* M, const P2* m, int count, const double* H, float* err) {
+    const float Hf[8] = {(float)H[0], (float)H[1], (float)H[2], (float)H[3], (float)H[4], (float)H[5], (float)H[6], (float)H[7]};
+    for (int i = 0; i < count; i++) {
+        const float ww = 1.f / (Hf[6] * M[i].x + Hf[7] * M[i].y + 1.f);
+        const float dx = (Hf[0] * M[i].x + Hf[1] * M[i].y + Hf[2]) * ww - m[i].x;
+        const float dy = (Hf[3] * M[i].x + Hf[4] * M[i].y + Hf[5]) * ww - m[i].y;
+        err[i] = dx * dx + dy * dy;
+    }
+}
+
 int ransac_update_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::max(p, 0.); p = std::min(p, 1.);
     ep = std::max(ep, 0.); ep = std::min(ep, 1.);
@@ -315,7 +326,7 @@ int orc_find_homography(const float* src_pts, const float* dst_pts, int n, int m
                         uint8_t* mask_out, int* found) {
     *found = 0;
     if (n < 4) return 3;
-    if (method != 0 && method != 8) return (method == 4 || method == 16) ? 7 : 3;
+    if (method != 0 && method != 8 && method != 4) return method == 16 ? 7 : 3;
     if (thr <= 0) thr = 3;
     std::vector<P2> src(n), dst(n);
     for (int i = 0; i < n; i++) { src[i] = {src_pts[2 * i], src_pts[2 * i + 1]}; dst[i] = {dst_pts[2 * i], dst_pts[2 * i + 1]}; }
@@ -323,6 +334,41 @@ int orc_find_homography(const float* src_pts, const float* dst_pts, int n, int m
     bool result = false;
     if (method == 0 || n == 4) {
         result = dlt(src.data(), dst.data(), n, H);
+    } else if (method == 4) {
+        // LMeDSPointSetRegistrator::run (calib3d/src/ptsetreg.cpp): fixed iteration count from an assumed
+        // 45% outlier ratio, model with the least median squared reprojection error, inliers from the robust sigma
+        const int modelPoints = 4;
+        const int niters = ransac_update_iters(0.995, 0.45, modelPoints, 2000);
+        Rng rng((uint64_t)-1);
+        std::vector<float> err(n);
+        double model[9], bestModel[9], minMedian = DBL_MAX;
+        P2 ms1[4], ms2[4];
+        for (int iter = 0; iter < niters; iter++) {
+            bool got = false;
+            for (int attempt = 0; attempt < 1000 && !got; attempt++) {
+                int idx[4];
+                for (int i = 0; i < modelPoints; i++) {
+                    int idx_i;
+                    for (idx_i = rng.uniform(0, n); std::find(idx, idx + i, idx_i) != idx + i; idx_i = rng.uniform(0, n)) {}
+                    idx[i] = idx_i;
+                    ms1[i] = src[idx_i]; ms2[i] = dst[idx_i];
+                }
+                got = check_subset(ms1, ms2, modelPoints);
+            }
+            if (!got) { if (iter == 0) { return 0; } break; }
+            if (!dlt(ms1, ms2, modelPoints, model)) continue;
+            reproj_errors(src.data(), dst.data(), n, model, err.data());
+            std::nth_element(err.begin(), err.begin() + n / 2, err.end());
+            const double median = err[n / 2];
+            if (median < minMedian) { minMedian = median; std::memcpy(bestModel, model, sizeof(model)); }
+        }
+        if (minMedian < DBL_MAX) {
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (n - modelPoints)) * std::sqrt(minMedian);
+            sigma = std::max(sigma, 0.001);
+            const int good = find_inliers(src.data(), dst.data(), n, bestModel, sigma, mask.data());
+            std::memcpy(H, bestModel, sizeof(bestModel));
+            result = good >= modelPoints;
+        }
     } else {
         const int modelPoints = 4;
         const double confidence = 0.995;
@@ -333,7 +379,7 @@ int orc_find_homography(const float* src_pts, const float* dst_pts, int n, int m
         P2 ms1[4], ms2[4];
         for (int iter = 0; iter < niters; iter++) {
             bool got = false;
-            for (int attempt = 0; attempt < 10000 && !got; attempt++) {
+            for (int attempt = 0; attempt < 1000 && !got; attempt++) {
                 int idx[4];
                 for (int i = 0; i < modelPoints; i++) {
                     int idx_i;
@@ -360,7 +406,7 @@ int orc_find_homography(const float* src_pts, const float* dst_pts, int n, int m
         for (int i = 0; i < n; i++) if (mask[i]) { s2.push_back(src[i]); d2.push_back(dst[i]); }
         const int np = (int)s2.size();
         if (np > 0) {
-            if (method == 8) dlt(s2.data(), d2.data(), np, H);
+            if (method == 8 || method == 4) dlt(s2.data(), d2.data(), np, H);
             lm_refine(s2.data(), d2.data(), np, H);
         }
     }

@@ -4,7 +4,7 @@ import pytest
 
 import oracle
 from libstacker_rs_amd import (InvalidParams, KeyPointMatchParameters, NotEnoughFiles, NotImplementedYet, OpenCvError,
-                               RANSAC, LMEDS, synth)
+                               RANSAC, LMEDS, RHO, synth)
 
 pytestmark = pytest.mark.gpu
 
@@ -81,7 +81,12 @@ def test_find_homography_known_answers(stacker):
     with pytest.raises(OpenCvError):
         stacker.find_homography(src[:3], dst[:3], RANSAC, 3.0)        # fewer than 4 pairs
     with pytest.raises(NotImplementedYet):
-        stacker.find_homography(src, dst, LMEDS, 3.0)
+        stacker.find_homography(src, dst, RHO, 3.0)
+    # LMEDS: least median of squares, < 45% outliers by construction of the method
+    Hl, maskl = stacker.find_homography(src, dst_o, LMEDS, 3.0)
+    Hlo, masklo = oracle.find_homography(src, dst_o, 4, 3.0)
+    assert np.array_equal(maskl, masklo) and np.allclose(Hl, Hlo, rtol=0, atol=1e-12)
+    assert maskl[::3].sum() == 0 and synth.corner_error(Hl, Ht, 640, 480) < 0.05
     # collinear points: no model
     line = np.c_[np.arange(20), 2 * np.arange(20)].astype(np.float32)
     Hn, _ = stacker.find_homography(line, line, RANSAC, 3.0)
@@ -178,3 +183,17 @@ def test_keypoint_match_scale_down_matches_oracle(stacker, kp_stack):
         assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-9)         # incl. the 4-entry rescale (utils.rs:236-239)
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 2.5    # coarser: features found at 0.62x
     assert np.max(np.abs(out - ref)) <= 4e-6
+
+
+def test_keypoint_match_lmeds_matches_oracle(stacker, kp_stack):
+    frames, G = kp_stack
+    p = KeyPointMatchParameters(LMEDS, 5.0, 0.80, 0.9)
+    dropped, out, stats = stacker.keypoint_match(list(frames[:3]), p, return_stats=True)
+    d_o, ref, Hs, status = oracle.keypoint_match(list(frames[:3]), method=4, details=True)
+    assert dropped == d_o == 0
+    for i in (1, 2):
+        assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-10)
+        assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 1.0
+    assert np.max(np.abs(out - ref)) <= 4e-6
+    with pytest.raises(NotImplementedYet):
+        stacker.keypoint_match(list(frames[:2]), KeyPointMatchParameters(RHO, 5.0, 0.80, 0.9))
