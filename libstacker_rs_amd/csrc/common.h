@@ -33,6 +33,7 @@ struct RefPlanes {
     const float* I;   // pointer to pixel (0,0) inside the padded plane
     const float* gx;
     const float* gy;
+    const float* gxy; // (gx, gy) interleaved, same padded geometry (2 floats per pixel)
     int stride;       // floats per padded row
     int w, h;
 };
@@ -121,7 +122,7 @@ hipError_t launch_convert_f32(const void* src, int depth, size_t n, float alpha,
 hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, size_t stride_bytes, int ksize,
                             float* out, int out_stride, hipStream_t s);
 // blurred plane (stride in_stride) -> padded I/gx/gy planes
-hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy,
+hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
                              int ref_stride, hipStream_t s);
 // variant: 1 = LDS-tiled (64x16 tiles, double-buffered footprint), 0 = direct global gathers
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s);

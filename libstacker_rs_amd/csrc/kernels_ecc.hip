@@ -31,6 +31,7 @@
 namespace stk {
 
 typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
 template <int MOTION> struct MotionTraits;
 template <> struct MotionTraits<STK_MOTION_TRANSLATION> { static constexpr int P = 2; };
@@ -302,8 +303,16 @@ __global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   
 #pragma unroll
     for (int k = 0; k < NR; k++) acc[k] = 0.f;
     double hacc = 0.0;                                        // lane L < 36: Hessian entry L
+    // Tap addressing: one unsigned 32-bit byte offset per pixel, shared by the planes, on top of scalar
+    // base pointers moved to the corner of the zero border (so the offset is never negative) — the
+    // loads take the `saddr + voffset` form and the per-pixel 64-bit pointer arithmetic disappears.
+    // gx and gy are read from the interleaved (gx, gy) plane: one 16-byte load per tap row.
     const int rs = a.ref.stride;
-    const int qw = (a.tw + 3) >> 2;
+    const int corner = REF_PAD * rs + REF_PAD;
+    const char* __restrict__ Ib = reinterpret_cast<const char*>(a.ref.I - corner);
+    const char* __restrict__ Gb = reinterpret_cast<const char*>(a.ref.gxy - 2 * (size_t)corner);
+    const char* __restrict__ Ib1 = Ib + (size_t)rs * 4;       // the tap row below: same vector offset, scalar base + 1 row
+    const char* __restrict__ Gb1 = Gb + (size_t)rs * 8;
     for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
         const float fy = (float)y;
         const float rowX = __builtin_fmaf(c.m1, fy, c.m2), rowY = __builtin_fmaf(c.m4, fy, c.m5);
@@ -312,12 +321,13 @@ __global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   
 #pragma unroll
         for (int k = 0; k < 6; k++) { h2[k] = 0.f; h1[k] = 0.f; h0[k] = 0.f; }
         const float* trow = T + (size_t)y * a.templ_row_stride;
-        for (int qx = lane; qx < qw; qx += 64) {
-            const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
-#pragma unroll 2
+        // lanes take ADJACENT pixels (x = chunk + 64 j + lane): the 64 tap addresses of a load are then nearly
+        // contiguous (3-5 cache lines per wave-load instead of 8-16 with one quad per lane)
+        for (int xb = 0; xb < a.tw; xb += 256) {
+#pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int x = qx * 4 + j;
-                const float tval = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
+                const int x = xb + j * 64 + lane;
+                const float tval = x < a.tw ? trow[x] : 0.f;
                 if (x < a.tw) {
                     const float fx = (float)x;
                     float sx = __builtin_fmaf(c.m0, fx, rowX), sy = __builtin_fmaf(c.m3, fx, rowY);
@@ -327,15 +337,15 @@ __global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   
                     sx *= rw; sy *= rw;
                     const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
                     const float ax = sx - flx, ay = sy - fly;
-                    const int ix = (int)__builtin_fminf(__builtin_fmaxf(flx, -2.0f), c.fiw);
-                    const int iy = (int)__builtin_fminf(__builtin_fmaxf(fly, -2.0f), c.fih);
-                    const int off = iy * rs + ix;
-                    const f32x2_a4 i0 = *(const f32x2_a4*)(a.ref.I + off), i1 = *(const f32x2_a4*)(a.ref.I + off + rs);
-                    const f32x2_a4 x0 = *(const f32x2_a4*)(a.ref.gx + off), x1 = *(const f32x2_a4*)(a.ref.gx + off + rs);
-                    const f32x2_a4 y0 = *(const f32x2_a4*)(a.ref.gy + off), y1 = *(const f32x2_a4*)(a.ref.gy + off + rs);
+                    // clamp into the zero border with one v_med3_f32 each; NaN -> -2 (all taps zero)
+                    const int ix = (int)__builtin_amdgcn_fmed3f(flx, -2.0f, c.fiw);
+                    const int iy = (int)__builtin_amdgcn_fmed3f(fly, -2.0f, c.fih);
+                    const unsigned bo = (unsigned)(__mul24(iy, rs) + ix + corner) << 2;
+                    const f32x2_a4 i0 = *(const f32x2_a4*)(Ib + bo), i1 = *(const f32x2_a4*)(Ib1 + bo);
+                    const f32x4_a8 g0 = *(const f32x4_a8*)(Gb + 2u * bo), g1 = *(const f32x4_a8*)(Gb1 + 2u * bo);
                     const float Iw = bilerp4(i0.x, i0.y, i1.x, i1.y, ax, ay);
-                    const float gxw = bilerp4(x0.x, x0.y, x1.x, x1.y, ax, ay);
-                    const float gyw = bilerp4(y0.x, y0.y, y1.x, y1.y, ax, ay);
+                    const float gxw = bilerp4(g0.x, g0.z, g1.x, g1.z, ax, ay);
+                    const float gyw = bilerp4(g0.y, g0.w, g1.y, g1.w, ax, ay);
                     bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
                     if (!inside) {
                         const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);

@@ -144,7 +144,7 @@ hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, si
 // ---- reference planes -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ref_planes_kernel(const float* __restrict__ b, int in_stride, int w, int h,
                                                          float* __restrict__ I, float* __restrict__ gx,
-                                                         float* __restrict__ gy, int rs) {
+                                                         float* __restrict__ gy, float* __restrict__ gxy, int rs) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const float* row = b + (size_t)y * in_stride;
@@ -152,14 +152,17 @@ __global__ __launch_bounds__(256) void ref_planes_kernel(const float* __restrict
     const float* dn = b + (size_t)reflect101(y + 1, h) * in_stride;
     const size_t o = (size_t)y * rs + x;
     I[o] = row[x];
-    gx[o] = -0.5f * row[reflect101(x - 1, w)] + 0.5f * row[reflect101(x + 1, w)];
-    gy[o] = -0.5f * up[x] + 0.5f * dn[x];
+    const float vx = -0.5f * row[reflect101(x - 1, w)] + 0.5f * row[reflect101(x + 1, w)];
+    const float vy = -0.5f * up[x] + 0.5f * dn[x];
+    gx[o] = vx;
+    gy[o] = vy;
+    *reinterpret_cast<float2*>(gxy + 2 * o) = make_float2(vx, vy);   // interleaved copy for the row-factorised ECC pass
 }
 
-hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy,
+hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
                              int ref_stride, hipStream_t s) {
     dim3 grid((w + 255) / 256, h);
-    ref_planes_kernel<<<grid, 256, 0, s>>>(blurred, in_stride, w, h, I, gx, gy, ref_stride);
+    ref_planes_kernel<<<grid, 256, 0, s>>>(blurred, in_stride, w, h, I, gx, gy, gxy, ref_stride);
     return hipGetLastError();
 }
 

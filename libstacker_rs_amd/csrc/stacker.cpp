@@ -201,7 +201,7 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     }
     nb = std::max(8, (nb / 8) * 8);
     pl.nb = nb;
-    HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 3 * sizeof(float)));
+    HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 5 * sizeof(float)));
     HIP_TRY(ctx->blur_tmp.reserve(pl.templ_plane_stride * sizeof(float)));
     // + slack: the tiled kernel copies whole 64-float tile rows, which may run past the last row's end
     HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1) + 1024));
@@ -216,10 +216,11 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
 static stk_status ecc_prepare_reference(stk_ctx* ctx, const EccPlan& pl, const void* img, int depth, int cn,
                                         size_t stride_bytes, int gauss) {
     HIP_TRY(launch_grey_blur(img, depth, cn, pl.w, pl.h, stride_bytes, gauss, ctx->blur_tmp.as<float>(), pl.templ_row_stride, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->ref.p, 0, pl.ref_plane_floats * 3 * sizeof(float), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->ref.p, 0, pl.ref_plane_floats * 5 * sizeof(float), ctx->stream));
     float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
+    float* gxy = ctx->ref.as<float>() + 3 * pl.ref_plane_floats + 2 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
     HIP_TRY(launch_ref_planes(ctx->blur_tmp.as<float>(), pl.templ_row_stride, pl.w, pl.h, base, base + pl.ref_plane_floats,
-                              base + 2 * pl.ref_plane_floats, pl.ref_stride, ctx->stream));
+                              base + 2 * pl.ref_plane_floats, gxy, pl.ref_stride, ctx->stream));
     return STK_OK;
 }
 
@@ -230,7 +231,8 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     if (pl.n_templates == 0) return STK_OK;
     EccIterArgs a{};
     const float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
-    a.ref = RefPlanes{base, base + pl.ref_plane_floats, base + 2 * pl.ref_plane_floats, pl.ref_stride, pl.w, pl.h};
+    const float* gxy = ctx->ref.as<float>() + 3 * pl.ref_plane_floats + 2 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
+    a.ref = RefPlanes{base, base + pl.ref_plane_floats, base + 2 * pl.ref_plane_floats, gxy, pl.ref_stride, pl.w, pl.h};
     a.templates = ctx->templates.as<float>();
     a.templ_plane_stride = pl.templ_plane_stride;
     a.templ_row_stride = pl.templ_row_stride;
