@@ -277,7 +277,15 @@ __constant__ unsigned char c_hess_src[36] = {0, 1, 2, 6, 7, 8, 6, 7,  3, 4, 7, 9
 __constant__ unsigned char c_hess_ypow[36] = {0, 0, 0, 1, 1, 1, 0, 0,  0, 0, 1, 1, 1, 0, 0,  0, 1, 1, 1, 0, 0,
                                                2, 2, 2, 1, 1,  2, 2, 1, 1,  2, 1, 1,  0, 0,  0};
 
-__global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   // 4 waves/SIMD: <= 128 VGPRs
+// one pixel in flight between the two pipeline stages of the row-factorised pass
+struct H8Px {
+    float sx, sy, rw, ax, ay, tval;
+    f32x2_a4 i0, i1;
+    f32x4_a8 g0, g1;
+    int x;
+};
+
+__global__ __launch_bounds__(256, 3) void ecc_iter_h8_kernel(EccIterArgs a) {   // 3 workgroups per CU: <= 168 VGPRs
     constexpr int MOTION = STK_MOTION_HOMOGRAPHY;
     constexpr int P = 8, NH = 36, NR = 3 * P + 6, NS = NH + NR;   // NR = 30 per-lane sums besides the Hessian
     // fused launch: the FIRST solve_n workgroups (dispatched first, so they run next to the pixel pass rather
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   
     const char* __restrict__ Gb = reinterpret_cast<const char*>(a.ref.gxy - 2 * (size_t)corner);
     const char* __restrict__ Ib1 = Ib + (size_t)rs * 4;       // the tap row below: same vector offset, scalar base + 1 row
     const char* __restrict__ Gb1 = Gb + (size_t)rs * 8;
+    const int nchunk = (a.tw + 63) >> 6;
     for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
         const float fy = (float)y;
         const float rowX = __builtin_fmaf(c.m1, fy, c.m2), rowY = __builtin_fmaf(c.m4, fy, c.m5);
@@ -321,69 +330,81 @@ __global__ __launch_bounds__(256, 4) void ecc_iter_h8_kernel(EccIterArgs a) {   
 #pragma unroll
         for (int k = 0; k < 6; k++) { h2[k] = 0.f; h1[k] = 0.f; h0[k] = 0.f; }
         const float* trow = T + (size_t)y * a.templ_row_stride;
-        // lanes take ADJACENT pixels (x = chunk + 64 j + lane): the 64 tap addresses of a load are then nearly
-        // contiguous (3-5 cache lines per wave-load instead of 8-16 with one quad per lane)
-        for (int xb = 0; xb < a.tw; xb += 256) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = xb + j * 64 + lane;
-                const float tval = x < a.tw ? trow[x] : 0.f;
-                if (x < a.tw) {
-                    const float fx = (float)x;
-                    float sx = __builtin_fmaf(c.m0, fx, rowX), sy = __builtin_fmaf(c.m3, fx, rowY);
-                    const float rw = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m6, fx, rowW));
-                    const float rden = rw;
-                    const float hx = -sx * rden, hy = -sy * rden;
-                    sx *= rw; sy *= rw;
-                    const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
-                    const float ax = sx - flx, ay = sy - fly;
-                    // clamp into the zero border with one v_med3_f32 each; NaN -> -2 (all taps zero)
-                    const int ix = (int)__builtin_amdgcn_fmed3f(flx, -2.0f, c.fiw);
-                    const int iy = (int)__builtin_amdgcn_fmed3f(fly, -2.0f, c.fih);
-                    const unsigned bo = (unsigned)(__mul24(iy, rs) + ix + corner) << 2;
-                    const f32x2_a4 i0 = *(const f32x2_a4*)(Ib + bo), i1 = *(const f32x2_a4*)(Ib1 + bo);
-                    const f32x4_a8 g0 = *(const f32x4_a8*)(Gb + 2u * bo), g1 = *(const f32x4_a8*)(Gb1 + 2u * bo);
-                    const float Iw = bilerp4(i0.x, i0.y, i1.x, i1.y, ax, ay);
-                    const float gxw = bilerp4(g0.x, g0.z, g1.x, g1.z, ax, ay);
-                    const float gyw = bilerp4(g0.y, g0.w, g1.y, g1.w, ax, ay);
-                    bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
-                    if (!inside) {
-                        const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
-                        inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
-                        const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
-                                          (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
-                        if (edge) inside = nearest_inside_exact<MOTION>(x, y, sl->warp, c.iw, c.ih);
-                    }
-                    const float mf = inside ? 1.0f : 0.0f;
-                    const float ja = gxw * rden, jb = gyw * rden;
-                    const float jt = hx * ja + hy * jb;
-                    // Hessian: X-moments of the six products
-                    const float qv[6] = {ja * ja, ja * jb, ja * jt, jb * jb, jb * jt, jt * jt};
-                    const float xx = fx * fx;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        h2[k] = __builtin_fmaf(qv[k], xx, h2[k]);
-                        h1[k] = __builtin_fmaf(qv[k], fx, h1[k]);
-                        h0[k] += qv[k];
-                    }
-                    const float J[8] = {ja * fx, jb * fx, jt * fx, ja * fy, jb * fy, jt * fy, ja, jb};
-                    const float u = inside ? Iw - c.cI : Iw;
-                    const float v = inside ? tval - c.cT : 0.0f;
-#pragma unroll
-                    for (int k = 0; k < P; k++) {
-                        acc[k] = __builtin_fmaf(J[k], u, acc[k]);
-                        acc[P + k] = __builtin_fmaf(J[k], v, acc[P + k]);
-                        acc[2 * P + k] = __builtin_fmaf(J[k], mf, acc[2 * P + k]);
-                    }
-                    const float um = u * mf;
-                    acc[3 * P + 0] += mf;
-                    acc[3 * P + 1] += um;
-                    acc[3 * P + 2] = __builtin_fmaf(um, u, acc[3 * P + 2]);
-                    acc[3 * P + 3] += v;
-                    acc[3 * P + 4] = __builtin_fmaf(v, v, acc[3 * P + 4]);
-                    acc[3 * P + 5] = __builtin_fmaf(um, v, acc[3 * P + 5]);
-                }
+        // lanes take ADJACENT pixels (x = 64 k + lane): the 64 tap addresses of a load are then nearly
+        // contiguous (3-5 cache lines per wave-load instead of 8-16 with one quad per lane).
+        // Two-stage software pipeline: the coordinates and the four loads of pixel k+1 are issued (stage A)
+        // before the ~70 arithmetic instructions of pixel k (stage B), so a wave always has one pixel's
+        // gathers in flight behind its own arithmetic instead of relying on the other 2 waves of the SIMD.
+        // (A third pixel in flight was measured: 168 VGPRs, 1% faster — not worth sitting on the register limit.)
+        auto stage_a = [&](int x, H8Px& p) {
+            const int xc = min(x, a.tw - 1);                  // past the row end: a harmless repeat, skipped in stage B
+            p.x = x;
+            p.tval = trow[xc];
+            const float fx = (float)xc;
+            float sx = __builtin_fmaf(c.m0, fx, rowX), sy = __builtin_fmaf(c.m3, fx, rowY);
+            const float rw = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m6, fx, rowW));
+            p.rw = rw;
+            sx *= rw; sy *= rw;                               // hatX = -X'/den and hatY = -Y'/den are exactly -sx, -sy (den == w)
+            p.sx = sx; p.sy = sy;
+            const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
+            p.ax = sx - flx; p.ay = sy - fly;
+            // clamp into the zero border with one v_med3_f32 each; NaN -> -2 (all taps zero)
+            const int ix = (int)__builtin_amdgcn_fmed3f(flx, -2.0f, c.fiw);
+            const int iy = (int)__builtin_amdgcn_fmed3f(fly, -2.0f, c.fih);
+            const unsigned bo = (unsigned)(__mul24(iy, rs) + ix + corner) << 2;
+            p.i0 = *(const f32x2_a4*)(Ib + bo); p.i1 = *(const f32x2_a4*)(Ib1 + bo);
+            p.g0 = *(const f32x4_a8*)(Gb + 2u * bo); p.g1 = *(const f32x4_a8*)(Gb1 + 2u * bo);
+        };
+        auto stage_b = [&](const H8Px& p) {
+            if (p.x >= a.tw) return;
+            const float fx = (float)p.x, sx = p.sx, sy = p.sy, rden = p.rw, tval = p.tval;
+            const float Iw = bilerp4(p.i0.x, p.i0.y, p.i1.x, p.i1.y, p.ax, p.ay);
+            const float gxw = bilerp4(p.g0.x, p.g0.z, p.g1.x, p.g1.z, p.ax, p.ay);
+            const float gyw = bilerp4(p.g0.y, p.g0.w, p.g1.y, p.g1.w, p.ax, p.ay);
+            bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
+            if (!inside) {
+                const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
+                inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
+                const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
+                                  (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
+                if (edge) inside = nearest_inside_exact<MOTION>(p.x, y, sl->warp, c.iw, c.ih);
             }
+            const float mf = inside ? 1.0f : 0.0f;
+            const float ja = gxw * rden, jb = gyw * rden;
+            const float jt = (-sx) * ja + (-sy) * jb;
+            // Hessian: X-moments of the six products
+            const float qv[6] = {ja * ja, ja * jb, ja * jt, jb * jb, jb * jt, jt * jt};
+            const float xx = fx * fx;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                h2[k] = __builtin_fmaf(qv[k], xx, h2[k]);
+                h1[k] = __builtin_fmaf(qv[k], fx, h1[k]);
+                h0[k] += qv[k];
+            }
+            const float J[8] = {ja * fx, jb * fx, jt * fx, ja * fy, jb * fy, jt * fy, ja, jb};
+            const float u = inside ? Iw - c.cI : Iw;
+            const float v = inside ? tval - c.cT : 0.0f;
+#pragma unroll
+            for (int k = 0; k < P; k++) {
+                acc[k] = __builtin_fmaf(J[k], u, acc[k]);
+                acc[P + k] = __builtin_fmaf(J[k], v, acc[P + k]);
+                acc[2 * P + k] = __builtin_fmaf(J[k], mf, acc[2 * P + k]);
+            }
+            const float um = u * mf;
+            acc[3 * P + 0] += mf;
+            acc[3 * P + 1] += um;
+            acc[3 * P + 2] = __builtin_fmaf(um, u, acc[3 * P + 2]);
+            acc[3 * P + 3] += v;
+            acc[3 * P + 4] = __builtin_fmaf(v, v, acc[3 * P + 4]);
+            acc[3 * P + 5] = __builtin_fmaf(um, v, acc[3 * P + 5]);
+        };
+        H8Px p0, p1;
+        stage_a(lane, p0);
+        for (int k = 0; k < nchunk; k += 2) {
+            stage_a((k + 1) * 64 + lane, p1);
+            stage_b(p0);
+            stage_a((k + 2) * 64 + lane, p0);
+            stage_b(p1);
         }
         // end of row: wave-reduce the 18 X-moments, then lane L < 36 takes entry L times Y^j in f64
         float sel = 0.f;
