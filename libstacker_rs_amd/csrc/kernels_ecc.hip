@@ -277,6 +277,24 @@ __constant__ unsigned char c_hess_src[36] = {0, 1, 2, 6, 7, 8, 6, 7,  3, 4, 7, 9
 __constant__ unsigned char c_hess_ypow[36] = {0, 0, 0, 1, 1, 1, 0, 0,  0, 0, 1, 1, 1, 0, 0,  0, 1, 1, 1, 0, 0,
                                                2, 2, 2, 1, 1,  2, 2, 1, 1,  2, 1, 1,  0, 0,  0};
 
+// Sum over the 64 lanes with six DPP-modified adds (row_shr 1/2/4/8 inside each row of 16, then row_bcast 15 and 31
+// across rows; shifted-in lanes contribute 0), the total of lane 63 returned in a scalar register.
+// Fixed order, so deterministic; ds_bpermute-based shuffles cost an LDS round trip per step instead.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);      // row_shr:8  -> lane 15 of each row = row total
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // one pixel in flight between the two pipeline stages of the row-factorised pass
 struct H8Px {
     float sx, sy, rw, ax, ay, tval;
@@ -406,13 +424,12 @@ __global__ __launch_bounds__(256, 3) void ecc_iter_h8_kernel(EccIterArgs a) {   
             stage_a((k + 2) * 64 + lane, p0);
             stage_b(p1);
         }
-        // end of row: wave-reduce the 18 X-moments, then lane L < 36 takes entry L times Y^j in f64
+        // end of row: wave-reduce the 18 X-moments with DPP adds (no LDS traffic), total read from lane 63 into a
+        // scalar register; then lane L < 36 takes entry L times Y^j in f64
         float sel = 0.f;
 #pragma unroll
         for (int k = 0; k < 18; k++) {
-            float r = k < 6 ? h2[k] : k < 12 ? h1[k - 6] : h0[k - 12];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+            const float r = wave_sum_dpp(k < 6 ? h2[k] : k < 12 ? h1[k - 6] : h0[k - 12]);
             sel = (hsrc == k) ? r : sel;
         }
         const double dy = (double)fy;
