@@ -82,10 +82,11 @@ struct EccIterArgs {
     int nb;                      // blocks per slot (multiple of 8)
     double* partials;            // [all slots][nsums][nb]
     // fused launches (variants 0 and 3): the slots are split in two groups that alternate; while one group's
-    // pixel pass runs, `solve_n` extra workgroups solve the OTHER group's previous pass (its partials are
-    // complete: they were written by the previous launch), so the solve latency is hidden.
+    // pixel pass runs, workgroups of that launch first solve the OTHER group's previous pass (its partials are
+    // complete: they were written by the previous launch), so the solve latency is hidden (kernels_ecc.hip).
     int slot0;
     int solve_slot0, solve_n;
+    int solve_first;             // 1: the first regions' workgroups solve (oversubscribed grid), 0: the last regions'
     int motion;
     EccCriteria crit;
     EccQueue* queue;

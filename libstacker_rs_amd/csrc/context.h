@@ -33,7 +33,7 @@ struct stk_ctx {
     int opt_ecc_fused = 0;        // variants 0/3: run the solve step in extra workgroups of the other slot group's pixel pass (two
                                   // alternating slot groups). Off by default: with 32 frames per GPU the longer end-of-stack tail
                                   // (8 slots draining) costs more than the hidden 20 us solve gains (measured r01: 1.87k vs 1.97k fps)
-    int opt_ecc_blocks = 768;     // total workgroups of one ECC iteration launch (all slots)
+    int opt_ecc_blocks = 1152;     // total workgroups of one ECC iteration launch (all slots)
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = row-factorised Hessian (homography, default), 0 = direct gathers,
                                   // 1 = LDS-tiled (LDS-DMA), 2 = row-sharing slots; see kernels_ecc.hip
     stk_timing timing{};

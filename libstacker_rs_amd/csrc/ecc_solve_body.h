@@ -64,24 +64,40 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
     //         issued before the first add so the HBM round trips overlap --------------------------------
     const double* base = a.partials + (size_t)slot * NS * a.nb;
     {
-        constexpr int KR = (ECC_MAX_SUMS + SOLVE_WAVES - 1) / SOLVE_WAVES;     // sums per wave (<= 5)
-        double acc[KR];
+        constexpr int KR = (ECC_MAX_SUMS + SOLVE_WAVES - 1) / SOLVE_WAVES;     // sums per wave
+        constexpr int KB = KR < 6 ? KR : 6;                                     // sums per batch (bounds the registers)
+        constexpr int JB = 5;                                                    // partials per lane and sum in flight
+        const int nbi = (a.nb + 63) >> 6;
+        for (int r0 = 0; r0 < KR; r0 += KB) {
+            double acc[KB];
 #pragma unroll
-        for (int r = 0; r < KR; r++) acc[r] = 0;
-        for (int b = lane; b < a.nb; b += 64) {
+            for (int r = 0; r < KB; r++) acc[r] = 0;
+            for (int j0 = 0; j0 < nbi; j0 += JB) {
+                // all KB x JB loads of the batch are issued before the first add (one memory round trip instead of
+                // JB); the adds keep the ascending-block order, out-of-range entries add +0
+                double v[KB][JB];
 #pragma unroll
-            for (int r = 0; r < KR; r++) {
-                const int k = wave + SOLVE_WAVES * r;
-                if (k < NS) acc[r] += base[(size_t)k * a.nb + b];
+                for (int j = 0; j < JB; j++) {
+                    const int b = lane + 64 * (j0 + j);
+#pragma unroll
+                    for (int r = 0; r < KB; r++) {
+                        const int k = wave + SOLVE_WAVES * (r0 + r);
+                        v[r][j] = (b < a.nb && k < NS) ? base[(size_t)k * a.nb + b] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < JB; j++)
+#pragma unroll
+                    for (int r = 0; r < KB; r++) acc[r] += v[r][j];
             }
-        }
 #pragma unroll
-        for (int r = 0; r < KR; r++) {
-            double v = acc[r];
+            for (int r = 0; r < KB; r++) {
+                double v = acc[r];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            const int k = wave + SOLVE_WAVES * r;
-            if (lane == 0 && k < NS) S[k] = v;
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                const int k = wave + SOLVE_WAVES * (r0 + r);
+                if (lane == 0 && k < NS) S[k] = v;
+            }
         }
     }
     __syncthreads();

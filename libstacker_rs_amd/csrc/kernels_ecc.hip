@@ -204,6 +204,22 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NS], const EccIt
     }
 }
 
+// Fused schedule: two slot groups alternate; while this launch runs the pixel pass of one group, the OTHER
+// group's previous pass is solved by workgroups of this launch — not extra ones, but workgroups that also own
+// template rows. Which ones depends on the grid (a.solve_first):
+//  * more workgroups than the chip holds at once (default, 1152 on 256 CUs x 3): the FIRST regions, which are
+//    dispatched at t = 0 — the solve is over long before the launch ends and the hardware dispatcher balances the rest;
+//  * exactly one resident wave of workgroups: the LAST regions, which own the fewest template rows (rows are dealt
+//    round-robin: with 2160 rows over 768 waves they have 2 rows where the first have 3) — the solve fits their slack.
+// Done before the idle-slot check: an idle slot's workgroups still serve.
+__device__ __forceinline__ void fused_solve_duty(const EccIterArgs& a, int slot, int region) {
+    if (a.solve_n <= 0) return;
+    const int r = a.solve_first ? region : a.nb - 1 - region;
+    const int duty = r * a.n_slots + (slot - a.slot0);
+    if (duty < a.solve_n)
+        ecc_solve_body<4>(a, a.solve_slot0 + duty, a.motion, a.crit, a.queue, a.results, a.init_warps);
+}
+
 __device__ __forceinline__ void load_slot_const(const EccSlot* sl, const EccIterArgs& a, SlotConst& c) {
     c.m0 = sl->warp[0]; c.m1 = sl->warp[1]; c.m2 = sl->warp[2];
     c.m3 = sl->warp[3]; c.m4 = sl->warp[4]; c.m5 = sl->warp[5];
@@ -223,16 +239,11 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
     constexpr int P = MotionTraits<MOTION>::P;
     constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
     // XCD-aware decode: bid = xcd + 8 * (slot + n_slots * (region / 8))
-    // fused launch: the FIRST solve_n workgroups (dispatched first, so they run next to the pixel pass rather
-    // than behind it) solve the other slot group's previous pass
-    if ((int)blockIdx.x < a.solve_n) {
-        ecc_solve_body<4>(a, a.solve_slot0 + (int)blockIdx.x, a.motion, a.crit, a.queue, a.results, a.init_warps);
-        return;
-    }
-    const int bid = (int)blockIdx.x - a.solve_n;
+    const int bid = (int)blockIdx.x;
     const int xcd = bid & 7, q = bid >> 3;
     const int slot = a.slot0 + q % a.n_slots;
     const int region = (q / a.n_slots) * 8 + xcd;
+    fused_solve_duty(a, slot, region);
     const EccSlot* sl = a.slots + slot;
     const int frame = sl->frame;
     if (frame < 0) return;                                    // idle slot: whole block leaves
@@ -306,16 +317,11 @@ struct H8Px {
 __global__ __launch_bounds__(256, 3) void ecc_iter_h8_kernel(EccIterArgs a) {   // 3 workgroups per CU: <= 168 VGPRs
     constexpr int MOTION = STK_MOTION_HOMOGRAPHY;
     constexpr int P = 8, NH = 36, NR = 3 * P + 6, NS = NH + NR;   // NR = 30 per-lane sums besides the Hessian
-    // fused launch: the FIRST solve_n workgroups (dispatched first, so they run next to the pixel pass rather
-    // than behind it) solve the other slot group's previous pass
-    if ((int)blockIdx.x < a.solve_n) {
-        ecc_solve_body<4>(a, a.solve_slot0 + (int)blockIdx.x, a.motion, a.crit, a.queue, a.results, a.init_warps);
-        return;
-    }
-    const int bid = (int)blockIdx.x - a.solve_n;
+    const int bid = (int)blockIdx.x;
     const int xcd = bid & 7, q = bid >> 3;
     const int slot = a.slot0 + q % a.n_slots;
     const int region = (q / a.n_slots) * 8 + xcd;
+    fused_solve_duty(a, slot, region);
     const EccSlot* sl = a.slots + slot;
     const int frame = sl->frame;
     if (frame < 0) return;
@@ -675,10 +681,10 @@ __global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
 
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
-    // variants 0 and 3 may carry a.solve_n extra workgroups (fused solve of the other slot group)
+    // variants 0 and 3: a.solve_n > 0 = fused solve of the other slot group inside this launch (fused_solve_duty)
     if (variant == 3 && motion == STK_MOTION_HOMOGRAPHY) {   // other motions: direct variant below
-        if (grid + a.solve_n <= 0) return hipSuccess;
-        ecc_iter_h8_kernel<<<grid + a.solve_n, 256, 0, s>>>(a);
+        if (grid <= 0) return hipSuccess;
+        ecc_iter_h8_kernel<<<grid, 256, 0, s>>>(a);
         return hipGetLastError();
     }
     if (variant == 2) {     // one workgroup = n_slots waves; a.nb workgroups in total (multiple of 8)
@@ -703,7 +709,7 @@ hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStr
         }
         return hipGetLastError();
     }
-    const int gridf = grid + a.solve_n;
+    const int gridf = grid;
     if (gridf <= 0) return hipSuccess;
     switch (motion) {
         case STK_MOTION_HOMOGRAPHY: ecc_iter_kernel<STK_MOTION_HOMOGRAPHY><<<gridf, 256, 0, s>>>(a); break;

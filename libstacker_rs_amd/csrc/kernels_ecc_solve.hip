@@ -18,7 +18,7 @@ constexpr int SOLVE_WAVES_STANDALONE = 16;
 
 __global__ __launch_bounds__(1024) void ecc_solve_kernel(EccIterArgs a, int motion, EccCriteria crit, EccQueue* queue,
                                                         EccFrameResult* results, const float* init_warps) {
-    ecc_solve_body<SOLVE_WAVES_STANDALONE>(a, (int)blockIdx.x, motion, crit, queue, results, init_warps);
+    ecc_solve_body<SOLVE_WAVES_STANDALONE>(a, a.slot0 + (int)blockIdx.x, motion, crit, queue, results, init_warps);
 }
 
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,

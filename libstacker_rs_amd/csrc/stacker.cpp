@@ -178,7 +178,8 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     }
     // Fused launches (variants 0 and 3): two groups of `slots` slots alternate, the solve of one group runs in
     // extra workgroups of the other group's pixel pass.
-    const bool fused = (ctx->opt_ecc_variant == 0 || ctx->opt_ecc_variant == 3) && ctx->opt_ecc_fused;
+    // (only when there are more frames than one group holds; a short stack iterates all its frames in one launch)
+    const bool fused = (ctx->opt_ecc_variant == 0 || ctx->opt_ecc_variant == 3) && ctx->opt_ecc_fused && n_templates > slots;
     pl.group_a = pl.group_b = 0;
     if (fused) {
         const int total = std::max(1, std::min(2 * slots, std::max(n_templates, 1)));
@@ -244,6 +245,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     EccQueue* q = ctx->queue.as<EccQueue>();
     EccFrameResult* r = ctx->results.as<EccFrameResult>();
     a.slot0 = 0; a.solve_slot0 = 0; a.solve_n = 0;
+    a.solve_first = pl.nb * std::max(pl.group_a, 1) > 768;   // 256 CUs x 3 resident workgroups of the pixel pass
     a.motion = pl.motion; a.crit = crit; a.queue = q; a.results = r; a.init_warps = nullptr;
     const bool fused = pl.group_a > 0;
     long long fused_n = 0;                                  // launches issued so far (selects the group)
@@ -262,13 +264,26 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
             for (auto& e : ctx->prof_ev) HIP_TRY(hipEventCreate(&e));
         }
         ctx->host_done[0] = ctx->host_done[1] = 0;
+        int seen_done = 0;                                  // latest polled value of the device-side completion counter
+        bool merged = false;
         while (!done) {
             while (inflight < 2) {
+                if (fused && !merged && fused_n > 0 && seen_done >= pl.n_templates - pl.group_a) {
+                    // Tail of the stack: every unfinished frame already sits in a slot and there are no more than one
+                    // group's worth of them. Alternating two mostly idle groups would cost a launch per group and
+                    // iteration, so close the pipeline (solve the group whose pass is still open) and continue with
+                    // all slots in one launch + one solve, as the unfused schedule does.
+                    const bool gb = ((fused_n - 1) & 1) != 0;
+                    a.slot0 = gb ? pl.group_a : 0; a.n_slots = gb ? pl.group_b : pl.group_a; a.solve_n = 0;
+                    HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
+                    a.slot0 = 0; a.n_slots = pl.n_slots; a.solve_slot0 = 0;
+                    merged = true;
+                }
                 for (int c = 0; c < chunk; c++) {
                     const bool timed = ctx->opt_profile >= 2 && prof_used + 2 <= ctx->prof_ev.size();
                     if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used], ctx->stream));
-                    if (fused) {
-                        // launch n iterates group n % 2 and, in extra workgroups, solves the other group's previous pass
+                    if (fused && !merged) {
+                        // launch n iterates group n % 2 and, in its last-region workgroups, solves the other group's previous pass
                         const bool gb = (fused_n & 1) != 0;
                         a.slot0 = gb ? pl.group_a : 0; a.n_slots = gb ? pl.group_b : pl.group_a;
                         a.solve_slot0 = gb ? 0 : pl.group_a;
@@ -277,7 +292,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                     }
                     HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->opt_ecc_variant, ctx->stream));
                     if (timed) { HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used + 1], ctx->stream)); prof_used += 2; }
-                    if (!fused) HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
+                    if (!fused || merged) HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
                 }
                 launched += chunk;
                 ctx->timing.ecc_iter_launches += chunk;
@@ -287,7 +302,8 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                 inflight++;
             }
             HIP_TRY(hipEventSynchronize(ctx->poll_ev[head]));
-            if (ctx->host_done[head] >= pl.n_templates) done = true;
+            seen_done = ctx->host_done[head];
+            if (seen_done >= pl.n_templates) done = true;
             head ^= 1; inflight--;
             if (!done && launched > max_launches)
                 return fail(ctx, STK_PROCESSING_ERROR, "ECC queue did not drain (internal error)");
