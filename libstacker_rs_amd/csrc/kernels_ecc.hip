@@ -8,19 +8,17 @@
 //  partials. OpenCV materialises ~150 f32 planes per iteration for the same result; here the
 //  algorithmic traffic is 16 B/px.
 //
-//  Three variants of the pass, same arithmetic per pixel (they differ in the f32 summation order only):
-//   * direct (variant 0, default — fastest as measured in round 1): one wave per template row, lanes
-//     stream aligned 16-byte template quads, every tap is a global gather; the overlap between
-//     neighbouring lanes and rows is absorbed by L1/L2.
-//   * tiled (variant 1): a workgroup walks 64x16-pixel tiles; the source footprint of a tile (bounding
-//     box of its four warped corners + margin) is copied for all three planes into LDS with LDS-DMA
-//     (global_load_lds_dwordx4), double-buffered, and every tap is an LDS read. Tiles whose
-//     footprint does not fit (large rotations / zooms) gather directly.
-//   * row-sharing (variant 2): the waves of a workgroup are the slots, all on the same template row.
-//  Measured (profiles/r01): the pass is bound by VALU issue with ~3 resident waves per
-//  SIMD (142 VGPRs: 66 accumulators), not by HBM or gather latency — staging through LDS, sharing
-//  rows between slots and prefetching the template each left the time unchanged or worse, while
-//  removing 35 of the ~126 VALU instructions per pixel scaled the time proportionally.
+//  Variants of the pass (option `ecc_variant`; same sums, they differ in the f32 summation order only):
+//   * 3 (default, homography): ecc_iter_h8_kernel — row-factorised Hessian, lane-adjacent pixels, taps through
+//     one 32-bit offset on scalar bases, two-stage software pipeline (see the comment above that kernel).
+//   * 0: direct — one wave per template row, lanes stream aligned 16-byte template quads, 66 per-lane
+//     accumulators, every tap a global gather. Used for translation / euclidean / affine.
+//   * 1: tiled — a workgroup walks 64x16-pixel tiles; the source footprint of a tile is copied for all three
+//     planes into LDS with LDS-DMA (global_load_lds_dwordx4), double-buffered, and every tap is an LDS read.
+//   * 2: row-sharing — the waves of a workgroup are the slots, all on the same template row.
+//  Measured: the pass is NOT HBM-bound (fabric traffic < algorithmic bytes: frame 0 is shared in
+//  L2/MALL); variants 1 and 2 and template prefetch left the time unchanged, removing VALU instructions scaled it
+//  proportionally, contiguous gathers and pipelining the loads bought the rest. 182 -> 100 us per 4-slot 4K launch.
 //
 //  Several frames ("slots") iterate concurrently in one launch. blockIdx is decoded so that the
 //  blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD and
