@@ -175,6 +175,10 @@ stk_status stk_grey(stk_ctx* ctx, const stk_frames* frame /* n==1 */, void* out)
 /* Mat::convert_to(CV_32F, alpha) utils.rs:133 (alpha = 1/255 there). */
 stk_status stk_convert_f32(stk_ctx* ctx, const stk_frames* frame /* n==1 */, double alpha,
                            float* out);
+/* One frame's whole ECC preparation as ecc_match runs it per frame: cvt_color(BGR2GRAY) (utils.rs:136-142) followed
+ * by findTransformECC's own GaussianBlur of the float image (lib.rs:769-777) in one fused pass. `out` is a tightly
+ * packed width x height f32 plane in the frame's location. BGR frames, 8-bit or f32. */
+stk_status stk_grey_blur_f32(stk_ctx* ctx, const stk_frames* frame /* n==1 */, int32_t ksize, float* out);
 /* GaussianBlur(float(grey), g x g, sigma 0, REFLECT_101) as findTransformECC's setup does. */
 stk_status stk_gaussian_blur_f32(stk_ctx* ctx, const void* grey, int32_t depth, int32_t width,
                                  int32_t height, int32_t location, int32_t ksize, float* out);

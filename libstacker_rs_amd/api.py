@@ -317,6 +317,19 @@ class Stacker:
         self._check(self._lib.stk_convert_f32(self._h, C.byref(m.c_frames), float(alpha), C.c_void_p(ptr)))
         return out
 
+    def grey_blur_f32(self, frame, ksize: int):
+        """cvt_color(BGR2GRAY) + findTransformECC's GaussianBlur of one frame, fused (the per-frame ECC preparation)."""
+        m = _Marshalled([frame])
+        if m.location == DEVICE:
+            import torch
+            out = torch.empty((m.h, m.w), dtype=torch.float32, device=m.torch_device)
+            ptr = out.data_ptr()
+        else:
+            out = np.empty((m.h, m.w), np.float32)
+            ptr = out.ctypes.data
+        self._check(self._lib.stk_grey_blur_f32(self._h, C.byref(m.c_frames), int(ksize), C.c_void_p(ptr)))
+        return out
+
     def gaussian_blur_f32(self, grey, ksize: int):
         g = np.ascontiguousarray(grey)
         h, w = g.shape

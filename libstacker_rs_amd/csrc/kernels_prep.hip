@@ -126,12 +126,120 @@ __global__ __launch_bounds__(256) void grey_blur_kernel(const T* __restrict__ sr
     }
 }
 
+// ---- fused grey + Gaussian blur, fast path: BGR u8, kernel size 3 / 5 / 7, 4-byte aligned rows ---------------
+// Same arithmetic as grey_blur_kernel (same grey formula, same tap order), different data movement:
+//  * a 128 x 32 output tile per workgroup; the BGR bytes of 4 pixels are three aligned dword loads (the tile starts
+//    4 px left of its first output so that every quad is 12-byte aligned), unpacked in registers;
+//  * LDS traffic in float4: the row pass reads 12 floats and writes 4 outputs per item, the column pass keeps a
+//    4-wide strip in registers and streams 16-byte stores, 512 contiguous bytes per row and 32 lanes.
+constexpr int FB_X = 128, FB_Y = 32, FB_HX = 4;           // outputs per tile; horizontal halo loaded (>= r, multiple of 4)
+constexpr int FB_GW = FB_X + 2 * FB_HX;                   // 136 floats per grey tile row
+
+template <int R>
+__global__ __launch_bounds__(256) void grey_blur_u8c3_kernel(const uint8_t* __restrict__ src, size_t stride, int w, int h,
+                                                             GaussTaps taps, float* __restrict__ out, int out_stride) {
+    constexpr int GH = FB_Y + 2 * R;
+    __shared__ __attribute__((aligned(16))) float G[GH * FB_GW];
+    __shared__ __attribute__((aligned(16))) float Rw[GH * FB_X];
+    const int x0 = blockIdx.x * FB_X, y0 = blockIdx.y * FB_Y;
+    const int tid = threadIdx.x;
+    float k[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; j++) k[j] = taps.k[j];
+
+    // phase 1: grey tile with halo, one pixel quad per item
+    constexpr int QW = FB_GW / 4;                          // 34 quads per row
+    for (int i = tid; i < GH * QW; i += 256) {
+        const int qy = i / QW, qx = i - qy * QW;
+        const int sy = reflect101(y0 - R + qy, h);
+        const int sx0 = x0 - FB_HX + 4 * qx;
+        const uint8_t* row = src + (size_t)sy * stride;
+        float4 g;
+        if (sx0 >= 0 && sx0 + 3 < w) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(row + (size_t)sx0 * 3);
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+            g.x = (float)grey_u8(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u);
+            g.y = (float)grey_u8(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u);
+            g.z = (float)grey_u8((d1 >> 16) & 255u, d1 >> 24, d2 & 255u);
+            g.w = (float)grey_u8((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24);
+        } else {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint8_t* q = row + (size_t)reflect101(sx0 + e, w) * 3;
+                v[e] = (float)grey_u8(q[0], q[1], q[2]);
+            }
+            g = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        *reinterpret_cast<float4*>(G + qy * FB_GW + 4 * qx) = g;
+    }
+    __syncthreads();
+
+    // phase 2: row filter, 4 outputs per item
+    for (int i = tid; i < GH * (FB_X / 4); i += 256) {
+        const int ty = i / (FB_X / 4), q = i - ty * (FB_X / 4);
+        const float* gp = G + ty * FB_GW + 4 * q;           // gp[4 + e] is the centre of output e
+        const float4 a = *reinterpret_cast<const float4*>(gp), b = *reinterpret_cast<const float4*>(gp + 4),
+                     c = *reinterpret_cast<const float4*>(gp + 8);
+        const float f[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float sacc = k[0] * f[4 + e];
+#pragma unroll
+            for (int j = 1; j <= R; j++) sacc += k[j] * (f[4 + e - j] + f[4 + e + j]);
+            o[e] = sacc;
+        }
+        *reinterpret_cast<float4*>(Rw + ty * FB_X + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+
+    // phase 3: column filter; thread = 4-wide strip x 4 output rows
+    {
+        const int strip = tid & 31, rg = tid >> 5;         // 32 strips, 8 row groups of 4 rows
+        float4 win[4 + 2 * R];
+#pragma unroll
+        for (int t = 0; t < 4 + 2 * R; t++) win[t] = *reinterpret_cast<const float4*>(Rw + (rg * 4 + t) * FB_X + 4 * strip);
+        const int x = x0 + 4 * strip;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int y = y0 + rg * 4 + e;
+            float4 sacc;
+            sacc.x = k[0] * win[e + R].x; sacc.y = k[0] * win[e + R].y; sacc.z = k[0] * win[e + R].z; sacc.w = k[0] * win[e + R].w;
+#pragma unroll
+            for (int j = 1; j <= R; j++) {
+                sacc.x += k[j] * (win[e + R - j].x + win[e + R + j].x);
+                sacc.y += k[j] * (win[e + R - j].y + win[e + R + j].y);
+                sacc.z += k[j] * (win[e + R - j].z + win[e + R + j].z);
+                sacc.w += k[j] * (win[e + R - j].w + win[e + R + j].w);
+            }
+            if (y < h) {
+                float* op = out + (size_t)y * out_stride + x;
+                if (x + 3 < w) *reinterpret_cast<float4*>(op) = sacc;
+                else {
+                    if (x < w) op[0] = sacc.x;
+                    if (x + 1 < w) op[1] = sacc.y;
+                    if (x + 2 < w) op[2] = sacc.z;
+                }
+            }
+        }
+    }
+}
+
 hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, size_t stride_bytes, int ksize,
                             float* out, int out_stride, hipStream_t s) {
     GaussTaps taps;
     if (!gaussian_taps(ksize, taps)) return hipErrorInvalidValue;
     const int r = taps.r;
     const size_t lds_bytes = (size_t)((BT_Y + 2 * r) * (BT_X + 2 * r) + (BT_Y + 2 * r) * BT_X) * sizeof(float);
+    if (depth == 8 && cn == 3 && r >= 1 && r <= 3 && stride_bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 &&
+        out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        dim3 fgrid((w + FB_X - 1) / FB_X, (h + FB_Y - 1) / FB_Y);
+        if (r == 1) grey_blur_u8c3_kernel<1><<<fgrid, 256, 0, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+        else if (r == 2) grey_blur_u8c3_kernel<2><<<fgrid, 256, 0, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+        else grey_blur_u8c3_kernel<3><<<fgrid, 256, 0, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+        return hipGetLastError();
+    }
     dim3 grid((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y);
     if (depth == 8 && cn == 3) grey_blur_kernel<uint8_t, 3><<<grid, 256, lds_bytes, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
     else if (depth == 8 && cn == 1) grey_blur_kernel<uint8_t, 1><<<grid, 256, lds_bytes, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);

@@ -585,6 +585,27 @@ stk_status stk_gaussian_blur_f32(stk_ctx* ctx, const void* grey, int32_t depth, 
     return STK_OK;
 }
 
+stk_status stk_grey_blur_f32(stk_ctx* ctx, const stk_frames* f, int32_t ksize, float* out) {
+    stk_status st = check_frames(ctx, f, true);
+    if (st) return st;
+    if (!out) return fail(ctx, STK_INVALID_PARAMS, "null output");
+    if (f->depth != 8 && f->depth != 32) return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: images must be 8-bit or f32");
+    if (ksize <= 0 || ksize % 2 == 0) return fail(ctx, STK_BACKEND_ERROR, "GaussianBlur: kernel size must be odd and positive");
+    if (ksize > 31) return fail(ctx, STK_NOT_IMPLEMENTED, "ksize > 31 is not supported");
+    (void)hipSetDevice(ctx->device);
+    std::vector<const void*> dev;
+    if ((st = resolve_frames(ctx, f, dev))) return st;
+    const int stride = (f->width + 3) & ~3;                   // the engine's template row stride
+    const size_t ob = (size_t)stride * f->height * 4;
+    HIP_TRY(ctx->blur_tmp.reserve(ob));
+    HIP_TRY(launch_grey_blur(dev[0], f->depth, f->channels, f->width, f->height, frame_row_bytes(f), ksize,
+                             ctx->blur_tmp.as<float>(), stride, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)f->width * 4, ctx->blur_tmp.p, (size_t)stride * 4, (size_t)f->width * 4, f->height,
+                             f->location == STK_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
 stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* input, int32_t depth, int32_t width,
                                   int32_t height, int32_t location, const stk_ecc_params* params, float* warp,
                                   double* rho, int32_t* iterations) {

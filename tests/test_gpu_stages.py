@@ -50,6 +50,28 @@ def test_gaussian_blur_tiny_image_reflects(stacker):
     assert np.array_equal(stacker.gaussian_blur_f32(g, 7), oracle.gaussian_blur_f32(g, 7))
 
 
+@pytest.mark.parametrize("shape", [(200, 300), (211, 333), (75, 520), (40, 8), (33, 4), (2160 // 8, 3840 // 8)])
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_fused_grey_blur_bit_exact(stacker, shape, ksize):
+    # the per-frame ECC preparation; (200,300)/(75,520)/... take the dword-load fast path (rows 4-byte aligned),
+    # (211,333) the generic one; tiles of 128x32 outputs are crossed in both directions
+    import torch
+    h, w = shape
+    img = _rng_img(h, w, 3, np.uint8, 7)
+    ref = oracle.gaussian_blur_f32(oracle.grey(img), ksize)
+    assert np.array_equal(stacker.grey_blur_f32(img, ksize), ref)
+    dev = stacker.grey_blur_f32(torch.from_numpy(img).cuda(), ksize)
+    assert np.array_equal(dev.cpu().numpy(), ref)
+
+
+def test_fused_grey_blur_f32_input_and_large_kernel(stacker):
+    img = _rng_img(60, 90, 3, np.float32, 8)
+    got = stacker.grey_blur_f32(img, 5)
+    np.testing.assert_allclose(got, oracle.gaussian_blur_f32(oracle.grey(img), 5), rtol=2e-6, atol=1e-6)
+    img8 = _rng_img(60, 90, 3, np.uint8, 9)
+    np.testing.assert_allclose(stacker.grey_blur_f32(img8, 9), oracle.gaussian_blur_f32(oracle.grey(img8), 9), rtol=2e-6, atol=1e-4)
+
+
 H_CASES = {
     "identity": np.eye(3),
     "shift_int": np.array([[1, 0, 5], [0, 1, -3], [0, 0, 1.0]]),
