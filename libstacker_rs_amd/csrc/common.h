@@ -60,6 +60,9 @@ struct EccQueue {
     int n_frames;       // number of templates
     int frames_done;
     int pad;
+#ifdef STK_SOLVE_TIMING
+    long long dbg[16];   // wall_clock64 phase deltas of the last solve of slot 0 (10 ns ticks), debug builds only
+#endif
 };
 
 struct EccCriteria {
@@ -81,6 +84,8 @@ struct EccIterArgs {
     int n_slots;                 // slots iterated by this launch: slot0 .. slot0 + n_slots - 1
     int nb;                      // blocks per slot (multiple of 8)
     double* partials;            // [all slots][nsums][nb]
+    double* sums;                // [all slots][ECC_MAX_SUMS]: the reduced sums, stage 1 -> stage 2 of the solve kernel
+    int* tickets;                // [all slots]: arrival counter of the solve kernel's stage-1 workgroups (self-resetting)
     // fused launches (variants 0 and 3): the slots are split in two groups that alternate; while one group's
     // pixel pass runs, workgroups of that launch first solve the OTHER group's previous pass (its partials are
     // complete: they were written by the previous launch), so the solve latency is hidden (kernels_ecc.hip).
@@ -130,7 +135,7 @@ hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStr
 constexpr int ECC_TILE_W = 64, ECC_TILE_H = 16;
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
                             EccFrameResult* results, hipStream_t s);
-hipError_t launch_ecc_init(EccSlot* slots, int n_slots, EccQueue* queue, int n_frames, EccFrameResult* results,
+hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
                            const float* init_warps /* n_frames*9 or null */, hipStream_t s);
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s);
 hipError_t launch_scale(const float* in, float* out, size_t n, float scale, hipStream_t s);

@@ -4,6 +4,12 @@
 #pragma once
 #include "common.h"
 
+#ifdef STK_SOLVE_TIMING
+#define STK_TICK(i) do { if (threadIdx.x == 0 && slot == a.slot0) queue->dbg[i] = wall_clock64(); } while (0)
+#else
+#define STK_TICK(i) do { } while (0)
+#endif
+
 namespace stk {
 
 __device__ inline void slot_take_next(EccSlot* sl, EccQueue* queue, const float* init_warps) {
@@ -44,7 +50,7 @@ __device__ inline void invert_small_f32(const float* S, int n, float* D) {
 
 // One workgroup of SOLVE_WAVES wavefronts solves one slot. Called by the stand-alone solve kernel (16 waves)
 // and, with 4 waves, by the extra workgroups of the fused iteration kernels (kernels_ecc.hip).
-template <int SOLVE_WAVES>
+template <int SOLVE_WAVES, bool PRE_REDUCED = false>
 __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, int motion, EccCriteria crit, EccQueue* queue,
                                                EccFrameResult* results, const float* init_warps) {
     EccSlot* sl = a.slots + slot;
@@ -62,8 +68,16 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
 
     // ---- 1. reduce block partials: 16 waves, wave w owns sums w, w+16, ...; all loads of a wave are
     //         issued before the first add so the HBM round trips overlap --------------------------------
+    // slot state needed at the very end: loaded now (uniform -> scalar loads) so the latency hides behind the reduction
+    const double prev_rho = sl->rho;
+    const int prev_iter = sl->iter;
+    float wm[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) wm[k] = sl->warp[k];
     const double* base = a.partials + (size_t)slot * NS * a.nb;
-    {
+    if constexpr (PRE_REDUCED) {
+        if (tid < NS) S[tid] = a.sums[(size_t)slot * ECC_MAX_SUMS + tid];      // stage 1 ran in the caller (kernels_ecc_solve.hip)
+    } else {
         constexpr int KR = (ECC_MAX_SUMS + SOLVE_WAVES - 1) / SOLVE_WAVES;     // sums per wave
         constexpr int KB = KR < 6 ? KR : 6;                                     // sums per batch (bounds the registers)
         constexpr int JB = 5;                                                    // partials per lane and sum in flight
@@ -101,6 +115,7 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
         }
     }
     __syncthreads();
+    STK_TICK(4);
 
     // ---- 2. statistics (every thread computes the same scalars; no divergence) ------------------
     const double cI = sl->cI, cT = sl->cT;
@@ -136,6 +151,7 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
         AB[r][c] = v;
     }
     __syncthreads();
+    STK_TICK(5);
 
     // ---- 3. inverse ------------------------------------------------------------------------------
     if (P <= 3) {
@@ -153,10 +169,18 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
         bool singular = false;
         for (int i = 0; i < P && !singular; i++) {
             int k = i;                                             // partial pivoting: strict '>' keeps the first maximum
-            float best = fabsf(AB[i][i]);
-            for (int j = i + 1; j < P; j++) { const float v = fabsf(AB[j][i]); if (v > best) { best = v; k = j; } }
+            float col[8];                                          // column i, all rows: independent LDS reads, one round trip
+#pragma unroll
+            for (int j = 0; j < 8; j++) col[j] = j < P ? AB[j][i] : 0.f;
+            float best = 0.f, piv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float v = fabsf(col[j]);
+                if (j == i) { best = v; piv = col[j]; }
+                else if (j > i && j < P && v > best) { best = v; k = j; piv = col[j]; }
+            }
             if (best < eps) { singular = true; break; }
-            const float d = -1 / AB[k][i];
+            const float d = -1 / piv;
             float nv[2];
 #pragma unroll
             for (int e = 0; e < 2; e++) {
@@ -178,44 +202,73 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
             __builtin_amdgcn_wave_barrier();
         }
         if (!singular) {
-            if (lane < P) {                                        // back substitution, one B column per lane
-                const int j = P + lane;
-                for (int i = P - 1; i >= 0; i--) {
-                    float sacc = AB[i][j];
-                    for (int k = i + 1; k < P; k++) sacc -= AB[i][k] * AB[k][j];
-                    AB[i][j] = sacc / AB[i][i];
+            // back substitution, one B column per lane, the solution kept in registers: the U entries are uniform
+            // LDS reads that do not depend on the running solution, so they are all in flight at once
+            // (same operations in the same order as the serial loop: sacc -= U[i][k] * x[k], then / U[i][i])
+            float x[8];
+#pragma unroll
+            for (int i = 7; i >= 0; i--) {
+                x[i] = 0.f;
+                if (i < P) {
+                    float sacc = AB[i][P + (lane < P ? lane : 0)];
+#pragma unroll
+                    for (int k = i + 1; k < 8; k++)
+                        if (k < P) sacc -= AB[i][k] * x[k];
+                    x[i] = sacc / AB[i][i];
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane < P * P) Hinv[lane] = AB[lane / P][P + lane % P];
+            if (lane < P) {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (i < P) Hinv[i * P + lane] = x[i];
+            }
         } else if (lane < P * P) Hinv[lane] = 0.f;
     }
     __syncthreads();
+    STK_TICK(6);
 
     // ---- 4. lambda, parameter update, loop control -------------------------------------------------
-    if (tid < P) { float s = 0; for (int l = 0; l < P; l++) s += Hinv[tid * P + l] * vec[0][l]; vec[2][tid] = s; }   // iph
+    if (tid < P) {                                             // iph
+        float sacc = 0;
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+            if (l < P) sacc += Hinv[tid * P + l] * vec[0][l];
+        vec[2][tid] = sacc;
+    }
     __syncthreads();
     if (tid != 0) return;
+    STK_TICK(7);
 
-    const double last_rho = sl->rho;
+    const double last_rho = prev_rho;
     double rho = correlation / (imgNorm * tmpNorm);
-    const int iter = sl->iter + 1;
+    const int iter = prev_iter + 1;
     int status = 0;
     bool finished = false;
     if (rho != rho) { status = 1; finished = true; }
     else {
+        // (loops over the fixed bound 8 with guards, fully unrolled: the LDS reads are then issued together instead of
+        //  one dependent round trip per term — this serial tail was 5 us of the 19 us solve)
         double dot_ip = 0, dot_tp = 0;
-        for (int k = 0; k < P; k++) { dot_ip += (double)vec[0][k] * vec[2][k]; dot_tp += (double)vec[1][k] * vec[2][k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < P) { dot_ip += (double)vec[0][k] * vec[2][k]; dot_tp += (double)vec[1][k] * vec[2][k]; }
         const double lambda_n = imgNorm * imgNorm - dot_ip;
         const double lambda_d = correlation - dot_tp;
         if (lambda_d <= 0.0) { rho = -1; status = 2; finished = true; }
         else {
             const float lamf = (float)(lambda_n / lambda_d);
             float epf[8], dp[8];
-            for (int k = 0; k < P; k++) epf[k] = (float)((double)lamf * dvec[1][k] - dvec[0][k]);
-            for (int k = 0; k < P; k++) { float s = 0; for (int l = 0; l < P; l++) s += Hinv[k * P + l] * epf[l]; dp[k] = s; }
-            float* m = sl->warp;
+#pragma unroll
+            for (int k = 0; k < 8; k++) epf[k] = k < P ? (float)((double)lamf * dvec[1][k] - dvec[0][k]) : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float sacc = 0;
+#pragma unroll
+                for (int l = 0; l < 8; l++)
+                    if (k < P && l < P) sacc += Hinv[k * P + l] * epf[l];
+                dp[k] = sacc;
+            }
+            float* m = wm;
             if (motion == STK_MOTION_HOMOGRAPHY) {
                 m[0] += dp[0]; m[3] += dp[1]; m[6] += dp[2]; m[1] += dp[3]; m[4] += dp[4]; m[7] += dp[5]; m[2] += dp[6]; m[5] += dp[7];
             } else if (motion == STK_MOTION_AFFINE) {
@@ -229,6 +282,8 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
                 m[3] = (float)sin(th);
                 m[1] = -m[3];
             }
+#pragma unroll
+            for (int k = 0; k < 9; k++) sl->warp[k] = wm[k];
         }
     }
     // for (i = 1; i <= nIter && fabs(rho - last_rho) >= eps; i++): would iteration iter+1 run?
@@ -237,9 +292,10 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
     sl->last_rho = last_rho;
     sl->rho = rho;
     sl->cI = imgMeanF; sl->cT = tmpMeanF;
+    STK_TICK(8);
     if (finished) {
         EccFrameResult* r = results + frame;
-        for (int k = 0; k < 9; k++) r->warp[k] = sl->warp[k];
+        for (int k = 0; k < 9; k++) r->warp[k] = wm[k];
         r->iters = iter; r->status = status; r->rho = rho;
         slot_take_next(sl, queue, init_warps);
         __threadfence();

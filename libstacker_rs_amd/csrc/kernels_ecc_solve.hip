@@ -14,33 +14,97 @@ namespace stk {
 #include "ecc_solve_body.h"
 namespace stk {
 
-constexpr int SOLVE_WAVES_STANDALONE = 16;
+// Stand-alone solve: two stages in one launch. The block partials of one slot are 66 x nb doubles (150 KB at 4K) and
+// a single CU pulls that from memory at only a few tens of GB/s, so stage 1 is spread over SOLVE_G workgroups per
+// slot (workgroup g reduces the sums k = g, g + G, ...; each sum by one wavefront in the same fixed order as before),
+// which publish their sums and take a ticket; the workgroup that draws the last ticket runs stage 2 (the normal
+// equations and the loop control) on the 66 published sums. Which workgroup that is does not affect any value.
+constexpr int SOLVE_G = 8;
 
-__global__ __launch_bounds__(1024) void ecc_solve_kernel(EccIterArgs a, int motion, EccCriteria crit, EccQueue* queue,
-                                                        EccFrameResult* results, const float* init_warps) {
-    ecc_solve_body<SOLVE_WAVES_STANDALONE>(a, a.slot0 + (int)blockIdx.x, motion, crit, queue, results, init_warps);
+__global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motion, EccCriteria crit, EccQueue* queue,
+                                                       EccFrameResult* results, const float* init_warps) {
+    const int slot = a.slot0 + (int)blockIdx.x / SOLVE_G, g = (int)blockIdx.x % SOLVE_G;
+#ifdef STK_SOLVE_TIMING
+    const long long t_start = wall_clock64();
+#endif
+    const int frame = a.slots[slot].frame;                  // tested only after the partial loads are in flight
+    const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
+    const int NS = P * (P + 1) / 2 + 3 * P + 6;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double* base = a.partials + (size_t)slot * NS * a.nb;
+    {
+        constexpr int KB = 3, JB = 5;                       // sums per wave (66 / 8 / 4 rounded up), partials per lane in flight
+        const int nbi = (a.nb + 63) >> 6;
+        double acc[KB];
+#pragma unroll
+        for (int r = 0; r < KB; r++) acc[r] = 0;
+        for (int j0 = 0; j0 < nbi; j0 += JB) {
+            double v[KB][JB];
+#pragma unroll
+            for (int j = 0; j < JB; j++) {
+                const int b = lane + 64 * (j0 + j);
+#pragma unroll
+                for (int r = 0; r < KB; r++) {
+                    const int k = g + SOLVE_G * (wave + 4 * r);
+                    v[r][j] = (b < a.nb && k < NS) ? base[(size_t)k * a.nb + b] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < JB; j++)
+#pragma unroll
+                for (int r = 0; r < KB; r++) acc[r] += v[r][j];
+        }
+#pragma unroll
+        for (int r = 0; r < KB; r++) {
+            double v = acc[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int k = g + SOLVE_G * (wave + 4 * r);
+            if (lane == 0 && k < NS && frame >= 0) a.sums[(size_t)slot * ECC_MAX_SUMS + k] = v;
+        }
+    }
+    if (frame < 0) return;                                  // idle slot: all of its workgroups leave, no ticket is drawn
+#ifdef STK_SOLVE_TIMING
+    const long long t_reduced = wall_clock64();
+#endif
+    __threadfence();                                         // publish this workgroup's sums before its ticket
+    __shared__ int last;
+    __syncthreads();
+    if (tid == 0) {
+        const int t = atomicAdd(&a.tickets[slot], 1);
+        last = (t == SOLVE_G - 1);
+        if (last) a.tickets[slot] = 0;                       // everyone has drawn: reset for the next launch
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                         // see the other workgroups' sums
+#ifdef STK_SOLVE_TIMING
+    if (tid == 0 && slot == a.slot0) { queue->dbg[0] = t_start; queue->dbg[1] = t_reduced; queue->dbg[2] = wall_clock64(); }
+#endif
+    ecc_solve_body<4, true>(a, slot, motion, crit, queue, results, init_warps);
 }
 
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
                             EccFrameResult* results, hipStream_t s) {
-    ecc_solve_kernel<<<a.n_slots, 64 * SOLVE_WAVES_STANDALONE, 0, s>>>(a, motion, crit, queue, results, nullptr);
+    ecc_solve_kernel<<<a.n_slots * SOLVE_G, 256, 0, s>>>(a, motion, crit, queue, results, nullptr);
     return hipGetLastError();
 }
 
-__global__ void ecc_init_kernel(EccSlot* slots, int n_slots, EccQueue* queue, int n_frames, EccFrameResult* results,
+__global__ void ecc_init_kernel(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
                                 const float* init_warps) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     queue->next_frame = 0; queue->n_frames = n_frames; queue->frames_done = 0; queue->pad = 0;
     for (int f = 0; f < n_frames; f++) { results[f].status = 3; results[f].iters = 0; results[f].rho = -1; }
     for (int s = 0; s < n_slots; s++) {
+        tickets[s] = 0;
         slots[s].last_rho = 0;
         slot_take_next(slots + s, queue, init_warps);
     }
 }
 
-hipError_t launch_ecc_init(EccSlot* slots, int n_slots, EccQueue* queue, int n_frames, EccFrameResult* results,
+hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
                            const float* init_warps, hipStream_t s) {
-    ecc_init_kernel<<<1, 64, 0, s>>>(slots, n_slots, queue, n_frames, results, init_warps);
+    ecc_init_kernel<<<1, 64, 0, s>>>(slots, n_slots, tickets, queue, n_frames, results, init_warps);
     return hipGetLastError();
 }
 

@@ -209,7 +209,7 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     HIP_TRY(ctx->slots.reserve(sizeof(EccSlot) * pl.n_slots));
     HIP_TRY(ctx->queue.reserve(sizeof(EccQueue)));
     HIP_TRY(ctx->results.reserve(sizeof(EccFrameResult) * std::max(n_templates, 1)));
-    HIP_TRY(ctx->partials.reserve(sizeof(double) * pl.n_slots * pl.nb * pl.nsums));
+    HIP_TRY(ctx->partials.reserve(sizeof(double) * pl.n_slots * ((size_t)pl.nb * pl.nsums + ECC_MAX_SUMS) + sizeof(int) * pl.n_slots));
     return STK_OK;
 }
 
@@ -242,6 +242,8 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     a.n_slots = pl.n_slots;
     a.nb = pl.nb;
     a.partials = ctx->partials.as<double>();
+    a.sums = a.partials + (size_t)pl.n_slots * pl.nb * pl.nsums;
+    a.tickets = reinterpret_cast<int*>(a.sums + (size_t)pl.n_slots * ECC_MAX_SUMS);
     EccQueue* q = ctx->queue.as<EccQueue>();
     EccFrameResult* r = ctx->results.as<EccFrameResult>();
     a.slot0 = 0; a.solve_slot0 = 0; a.solve_n = 0;
@@ -249,7 +251,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     a.motion = pl.motion; a.crit = crit; a.queue = q; a.results = r; a.init_warps = nullptr;
     const bool fused = pl.group_a > 0;
     long long fused_n = 0;                                  // launches issued so far (selects the group)
-    HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, q, pl.n_templates, r, init_warps_dev, ctx->stream));
+    HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, a.tickets, q, pl.n_templates, r, init_warps_dev, ctx->stream));
     if (crit.n_iter >= 1) {
         // Enqueue chunks of (iterate, solve) launches; keep two chunks in flight and poll the
         // device-side completion counter behind each. Launches after completion are no-ops.
@@ -316,6 +318,11 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     }
     HIP_TRY(hipMemcpyAsync(res.data(), r, sizeof(EccFrameResult) * pl.n_templates, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+#ifdef STK_SOLVE_TIMING
+    { EccQueue hq; (void)hipMemcpy(&hq, q, sizeof(hq), hipMemcpyDeviceToHost);
+      fprintf(stderr, "SOLVE_DBG stage1 %lld ticket %lld sums %lld stats %lld lu %lld iph %lld tail %lld (x10ns)\n", hq.dbg[1] - hq.dbg[0], hq.dbg[2] - hq.dbg[1],
+              hq.dbg[4] - hq.dbg[2], hq.dbg[5] - hq.dbg[4], hq.dbg[6] - hq.dbg[5], hq.dbg[7] - hq.dbg[6], hq.dbg[8] - hq.dbg[7]); }
+#endif
     if (crit.n_iter < 1)
         for (auto& e : res) { for (int k = 0; k < 9; k++) e.warp[k] = (k % 4 == 0) ? 1.f : 0.f; e.iters = 0; e.status = 0; e.rho = -1; }
     for (auto& e : res) ctx->timing.ecc_slot_iterations += e.iters;
