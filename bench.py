@@ -49,6 +49,9 @@ def main() -> None:
     ap.add_argument("--cpu-sample-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = cores+1)")
     ap.add_argument("--ecc-slots", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine tuning knob name=value (stk_set_option)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the reduce goes through gloo/CPU "
+                         "(checks the sharded code path, not a performance number)")
     ap.add_argument("--profile-launches", type=int, default=1,
                     help="1: bracket every ECC iteration launch with HIP events (roofline.achieved); 0: off")
     args = ap.parse_args()
@@ -64,11 +67,16 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from libstacker_rs_amd import (EccMatchParameters, KeyPointMatchParameters, MotionType, RANSAC, Stacker, synth)
     from libstacker_rs_amd.shard import shard_moving_frames
@@ -118,7 +126,12 @@ def main() -> None:
             last_stats = stats
         counts[0] = added
         counts[1] = dropped
-        if world > 1:
+        if world > 1 and args.rehearse_on_one_gpu:
+            a_c, c_c = acc.cpu(), counts.cpu()
+            dist.reduce(a_c, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(c_c, dst=0, op=dist.ReduceOp.SUM)
+            acc.copy_(a_c); counts.copy_(c_c)
+        elif world > 1:
             dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)          # RCCL over xGMI: the path's one exchange
             dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
             torch.cuda.current_stream().synchronize()              # acc is rewritten by the next step
@@ -140,7 +153,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -200,7 +213,7 @@ def main() -> None:
             "synthetic_generation_s": round(gen_s, 1),
         }
         # ---- CPU baseline: the oracle (a port of the reference's OpenCV/Rayon path) on host cores ----
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             import oracle
             cores = os.cpu_count() or 1
             use = min(cores, 32)
