@@ -1,5 +1,6 @@
 // context.h — the engine's per-GPU context (stk_ctx) and host helpers shared by stacker.cpp and keypoint.cpp.
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ struct stk_ctx {
     int opt_subpixel_bits = 0;
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
+    int opt_kp_workers = 8;       // host threads (each with its own stream and ORB workspace) of the keypoint path
     int opt_ecc_fused = 0;        // variants 0/3: run the solve step in extra workgroups of the other slot group's pixel pass (two
                                   // alternating slot groups). Off by default: with 32 frames per GPU the longer end-of-stack tail
                                   // (8 slots draining) costs more than the hidden 20 us solve gains (measured r01: 1.87k vs 1.97k fps)
@@ -44,10 +46,17 @@ struct stk_ctx {
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
     stk::KeypointWorkspace* kp = nullptr;
+    // keypoint path: moving frames are processed by `opt_kp_workers` host threads, each with its own workspace and
+    // stream (ORB is many small launches with host decisions in between: one frame cannot fill the GPU or hide the syncs)
+    std::vector<stk::KeypointWorkspace*> kp_workers;
+    std::vector<hipStream_t> kp_streams;
+    std::mutex err_mutex;
 };
 
 inline stk_status fail(stk_ctx* ctx, stk_status st, const std::string& msg) {
-    if (ctx) ctx->err = msg;
+    if (!ctx) return st;
+    std::lock_guard<std::mutex> lock(ctx->err_mutex);   // keypoint workers may fail concurrently
+    ctx->err = msg;
     return st;
 }
 #define HIP_TRY(expr)                                                                              \

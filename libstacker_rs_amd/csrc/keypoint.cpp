@@ -9,9 +9,11 @@
 // (<5 matches lib.rs:240, find_homography failure lib.rs:275, bad shape lib.rs:279, |det| < 1e-6
 // lib.rs:284) is skipped and counted; the sum is divided by n - dropped.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "context.h"
 #include "homography.h"
@@ -121,10 +123,8 @@ void retain_best(std::vector<T>& v, int n, F resp) {
 
 // ORB on an 8-bit grey image that already sits in level 0 of the workspace pyramid.
 // Descriptors are left on the device in `desc_dev` (n x 32 bytes).
-stk_status orb_run(stk_ctx* ctx, const OrbGeometry& g, uint8_t* desc_dev, size_t desc_cap_rows,
-                   std::vector<HostKeypoint>& out) {
-    KeypointWorkspace* ws = ctx->kp;
-    hipStream_t s = ctx->stream;
+stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const OrbGeometry& g, uint8_t* desc_dev,
+                   size_t desc_cap_rows, std::vector<HostKeypoint>& out) {
     uint8_t* pyr = ws->pyr.as<uint8_t>();
     uint8_t* score = ws->score.as<uint8_t>();
     OrbLevelState* st = ws->states.as<OrbLevelState>();
@@ -195,8 +195,7 @@ stk_status orb_run(stk_ctx* ctx, const OrbGeometry& g, uint8_t* desc_dev, size_t
     return STK_OK;
 }
 
-stk_status orb_prepare(stk_ctx* ctx, int w, int h, OrbGeometry& g) {
-    KeypointWorkspace* ws = ctx->kp;
+stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeometry& g) {
     orb_geometry(w, h, g);
     HIP_TRY(ws->pyr.reserve(g.pyr.total));
     HIP_TRY(ws->score.reserve(g.pyr.total));
@@ -207,7 +206,8 @@ stk_status orb_prepare(stk_ctx* ctx, int w, int h, OrbGeometry& g) {
     HIP_TRY(ws->states.reserve(sizeof(OrbLevelState) * ORB_LEVELS));
     if (!ws->host_sel) HIP_TRY(hipHostMalloc((void**)&ws->host_sel, sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS, hipHostMallocDefault));
     if (!ws->host_states) HIP_TRY(hipHostMalloc((void**)&ws->host_states, sizeof(OrbLevelState) * ORB_LEVELS, hipHostMallocDefault));
-    if (!ws->pattern_uploaded) { HIP_TRY(upload_orb_pattern(ORB_BIT_PATTERN_31)); ws->pattern_uploaded = true; }
+    // the BRIEF pattern lives in __constant__ memory of the module: uploaded once, by the main workspace
+    if (ws == ctx->kp && !ws->pattern_uploaded) { HIP_TRY(upload_orb_pattern(ORB_BIT_PATTERN_31)); ws->pattern_uploaded = true; }
     return STK_OK;
 }
 
@@ -227,14 +227,14 @@ stk_status stk_orb_detect_and_compute(stk_ctx* ctx, const uint8_t* grey, int32_t
     if (width >= 65536 || height >= 32768) return fail(ctx, STK_INVALID_PARAMS, "image too large for ORB");
     (void)hipSetDevice(ctx->device);
     OrbGeometry g;
-    stk_status st = orb_prepare(ctx, width, height, g);
+    stk_status st = orb_prepare(ctx, ctx->kp, width, height, g);
     if (st) return st;
     KeypointWorkspace* ws = ctx->kp;
     HIP_TRY(ws->desc.reserve(MAX_KP * 32));
     HIP_TRY(hipMemcpyAsync(ws->pyr.p, grey, (size_t)width * height,
                            location == STK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
     std::vector<HostKeypoint> kps;
-    if ((st = orb_run(ctx, g, ws->desc.as<uint8_t>(), MAX_KP, kps))) return st;
+    if ((st = orb_run(ctx, ws, ctx->stream, g, ws->desc.as<uint8_t>(), MAX_KP, kps))) return st;
     const int n = (int)std::min<size_t>(kps.size(), (size_t)max_keypoints);
     for (int i = 0; i < n; i++) {
         float* o = keypoints + (size_t)i * 7;
@@ -335,55 +335,60 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     if ((st = resolve_frames(ctx, frames, dev))) return st;
     const size_t rb = frame_row_bytes(frames);
     OrbGeometry g;
-    if ((st = orb_prepare(ctx, ew, eh, g))) return st;
-    KeypointWorkspace* ws = ctx->kp;
-    if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
-    // grey of frame i into level 0 of the ORB pyramid, through scale_image when scaling (utils.rs:186-214)
-    auto grey_level0 = [&](const void* frame) -> stk_status {
-        if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->pyr.p, ctx->stream)); return STK_OK; }
-        HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->gfull.p, ctx->stream));
-        HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, ws->pyr.as<uint8_t>(), ew, eh, ctx->stream));
+    if ((st = orb_prepare(ctx, ctx->kp, ew, eh, g))) return st;
+    KeypointWorkspace* ws0 = ctx->kp;
+    // per-workspace buffers beyond ORB's own: descriptors, 2-NN result, the full-size grey when scaling
+    auto prepare_match_buffers = [&](KeypointWorkspace* ws) -> stk_status {
+        if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
+        HIP_TRY(ws->desc.reserve(MAX_KP * 32));
+        HIP_TRY(ws->knn.reserve(MAX_KP * 16));
+        if (ws->host_knn_cap < MAX_KP * 4) {
+            if (ws->host_knn) (void)hipHostFree(ws->host_knn);
+            HIP_TRY(hipHostMalloc((void**)&ws->host_knn, MAX_KP * 16, hipHostMallocDefault));
+            ws->host_knn_cap = MAX_KP * 4;
+        }
+        return STK_OK;
+    };
+    // grey of a frame into level 0 of the ORB pyramid, through scale_image when scaling (utils.rs:186-214)
+    auto grey_level0 = [&](const void* frame, KeypointWorkspace* ws, hipStream_t s) -> stk_status {
+        if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->pyr.p, s)); return STK_OK; }
+        HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->gfull.p, s));
+        HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, ws->pyr.as<uint8_t>(), ew, eh, s));
         return STK_OK;
     };
     const double fix_sx = (double)w / (double)ew, fix_sy = (double)h / (double)eh;   // adjust_homography_for_scale_f64
-    HIP_TRY(ws->desc0.reserve(MAX_KP * 32));
-    HIP_TRY(ws->desc.reserve(MAX_KP * 32));
-    HIP_TRY(ws->knn.reserve(MAX_KP * 16));
-    if (ws->host_knn_cap < MAX_KP * 4) {
-        if (ws->host_knn) (void)hipHostFree(ws->host_knn);
-        HIP_TRY(hipHostMalloc((void**)&ws->host_knn, MAX_KP * 16, hipHostMallocDefault));
-        ws->host_knn_cap = MAX_KP * 4;
-    }
+    HIP_TRY(ws0->desc0.reserve(MAX_KP * 32));
+    if ((st = prepare_match_buffers(ws0))) return st;
     if (stats) std::memset(stats, 0, sizeof(stk_frame_stats) * n);
 
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     // reference frame: grey -> ORB, descriptors stay in desc0 (lib.rs:161-175)
-    if ((st = grey_level0(dev[0]))) return st;
+    if ((st = grey_level0(dev[0], ws0, ctx->stream))) return st;
     std::vector<HostKeypoint> kp0;
-    if ((st = orb_run(ctx, g, ws->desc0.as<uint8_t>(), MAX_KP, kp0))) return st;
+    if ((st = orb_run(ctx, ws0, ctx->stream, g, ws0->desc0.as<uint8_t>(), MAX_KP, kp0))) return st;   // ends synchronised
     const int n0 = (int)kp0.size();
     if (stats) { stats[0].n_keypoints = n0; stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1; }
+    const uint8_t* desc0 = ws0->desc0.as<uint8_t>();
 
-    std::vector<WarpFrame> wf;
-    wf.reserve(n);
-    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (add_reference) { wf.emplace_back(); make_warp_frame(wf.back(), dev[0], I3, 0); }
-    int dropped = 0;
-    std::vector<HostKeypoint> kp;
-    std::vector<Match> ms;
-    for (int i = 1; i < n; i++) {
-        if ((st = grey_level0(dev[i]))) return st;
-        if ((st = orb_run(ctx, g, ws->desc.as<uint8_t>(), MAX_KP, kp))) return st;
+    // one moving frame: ORB -> 2-NN against frame 0 -> ratio / sort / truncate -> homography. Independent of every
+    // other moving frame (lib.rs:185-290 is the body of a Rayon map), so frames are dealt to worker threads.
+    struct FrameResult { bool ok = false; double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; int nk = 0, n_matches = 0, n_inl = 0; };
+    std::vector<FrameResult> results(n);
+    auto process_frame = [&](int i, KeypointWorkspace* ws, hipStream_t s, std::vector<HostKeypoint>& kp, std::vector<Match>& ms) -> stk_status {
+        stk_status fs;
+        if ((fs = grey_level0(dev[i], ws, s))) return fs;
+        if ((fs = orb_run(ctx, ws, s, g, ws->desc.as<uint8_t>(), MAX_KP, kp))) return fs;
+        FrameResult& R = results[i];
         const int nk = (int)kp.size();
+        R.nk = nk;
         bool ok = true;
-        double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        int n_inl = 0;
+        double* H = R.H;
         ms.clear();
         if (n0 > 0) {
             // knn_match(query = frame-0 descriptors, train = frame-i descriptors, k = 2)  lib.rs:208-219
-            HIP_TRY(launch_knn2_hamming(ws->desc0.as<uint8_t>(), n0, ws->desc.as<uint8_t>(), nk, ws->knn.as<int>(), ctx->stream));
-            HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n0 * 16, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(launch_knn2_hamming(desc0, n0, ws->desc.as<uint8_t>(), nk, ws->knn.as<int>(), s));
+            HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n0 * 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
             const int* knn = ws->host_knn;
             for (int q = 0; q < n0; q++) {
                 if (knn[q * 4] < 0 || knn[q * 4 + 2] < 0) continue;                 // m.len() == 2
@@ -410,16 +415,67 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
                 const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
                 if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284 / 521 (on the small-image H)
                 else if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
-                for (uint8_t m : mask) n_inl += m;
+                for (uint8_t m : mask) R.n_inl += m;
             }
         }
-        if (stats) {
-            stats[i].status = ok ? 0 : 1; stats[i].n_keypoints = nk; stats[i].n_matches = (int)ms.size(); stats[i].n_inliers = n_inl;
-            for (int k = 0; k < 9; k++) stats[i].warp[k] = H[k];
+        R.ok = ok; R.n_matches = (int)ms.size();
+        return STK_OK;
+    };
+
+    const int n_moving = n - 1;
+    const int n_workers = std::max(1, std::min(ctx->opt_kp_workers, n_moving));
+    if (n_moving > 0 && n_workers == 1) {
+        std::vector<HostKeypoint> kp;
+        std::vector<Match> ms;
+        for (int i = 1; i < n; i++)
+            if ((st = process_frame(i, ws0, ctx->stream, kp, ms))) return st;
+    } else if (n_moving > 0) {
+        while ((int)ctx->kp_workers.size() < n_workers) {
+            hipStream_t ns = nullptr;
+            HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+            ctx->kp_streams.push_back(ns);
+            ctx->kp_workers.push_back(keypoint_workspace_create());
         }
-        if (!ok) { dropped++; continue; }
+        for (int k = 0; k < n_workers; k++) {                 // all allocation happens here, on the calling thread
+            OrbGeometry gk;
+            if ((st = orb_prepare(ctx, ctx->kp_workers[k], ew, eh, gk))) return st;
+            if ((st = prepare_match_buffers(ctx->kp_workers[k]))) return st;
+        }
+        HIP_TRY(hipDeviceSynchronize());                       // allocations / pattern upload visible to every stream
+        std::atomic<int> next{1};
+        std::vector<stk_status> wst(n_workers, STK_OK);
+        std::vector<std::thread> pool;
+        for (int k = 0; k < n_workers; k++)
+            pool.emplace_back([&, k]() {
+                (void)hipSetDevice(ctx->device);
+                std::vector<HostKeypoint> kp;
+                std::vector<Match> ms;
+                for (;;) {
+                    const int i = next.fetch_add(1);
+                    if (i >= n) break;
+                    const stk_status fs = process_frame(i, ctx->kp_workers[k], ctx->kp_streams[k], kp, ms);
+                    if (fs) { wst[k] = fs; next.store(n); break; }
+                }
+            });
+        for (auto& t : pool) t.join();
+        for (stk_status fs : wst) if (fs) return fs;           // the message of the (last) failing worker is in ctx->err
+    }
+
+    // fold order = frame order, whatever the workers' completion order was: the f32 sum is reproducible
+    std::vector<WarpFrame> wf;
+    wf.reserve(n);
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (add_reference) { wf.emplace_back(); make_warp_frame(wf.back(), dev[0], I3, 0); }
+    int dropped = 0;
+    for (int i = 1; i < n; i++) {
+        const FrameResult& R = results[i];
+        if (stats) {
+            stats[i].status = R.ok ? 0 : 1; stats[i].n_keypoints = R.nk; stats[i].n_matches = R.n_matches; stats[i].n_inliers = R.n_inl;
+            for (int k = 0; k < 9; k++) stats[i].warp[k] = R.H[k];
+        }
+        if (!R.ok) { dropped++; continue; }
         wf.emplace_back();
-        make_warp_frame(wf.back(), dev[i], H, 0);
+        make_warp_frame(wf.back(), dev[i], R.H, 0);
     }
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));

@@ -93,6 +93,8 @@ void stk_destroy(stk_ctx* ctx) {
                       &ctx->partials, &ctx->warpframes, &ctx->acc, &ctx->scratch, &ctx->init_warps})
         b->release();
     keypoint_workspace_destroy(ctx->kp);
+    for (auto* k : ctx->kp_workers) keypoint_workspace_destroy(k);
+    for (auto ks : ctx->kp_streams) if (ks) (void)hipStreamDestroy(ks);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->prof_ev) if (e) (void)hipEventDestroy(e);
@@ -124,6 +126,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
     else if (n == "ecc_variant") { if (value < 0 || value > 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0..3"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "ecc_fused") ctx->opt_ecc_fused = value != 0;
+    else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;

@@ -179,3 +179,31 @@ def test_ecc_match_scaling_down_matches_oracle(stacker):
         stacker.ecc_match(list(frames), PARAMS, scale_down_width=640.0)     # lib.rs:876
     with pytest.raises(InvalidParams):
         stacker.ecc_match(list(frames), PARAMS, scale_down_width=10.0)      # lib.rs:883
+
+
+def test_frame_sharded_ranks_reproduce_the_single_gpu_stack(stacker, small_stack):
+    # what bench.py / a multi-GPU host does: every rank folds its contiguous range of moving frames
+    # (rank 0 also frame 0), the f32 sums are added (RCCL reduce in production) and rank 0 divides by n.
+    # Per-frame warps are identical to the unsharded run bit for bit; the image differs only by the order of the adds.
+    import torch
+    from libstacker_rs_amd.shard import shard_moving_frames
+    frames, _ = small_stack
+    n = len(frames)
+    full, full_stats = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
+    for world in (2, 3):
+        total = torch.zeros((frames.shape[1], frames.shape[2], 3), dtype=torch.float32, device="cuda")
+        added_total = 0
+        for rank in range(world):
+            mine = shard_moving_frames(n, world, rank)
+            acc = torch.empty_like(total)
+            sub = torch.from_numpy(np.ascontiguousarray(frames[[0] + mine])).cuda()
+            added, stats = stacker.ecc_match_shard(sub, PARAMS, rank == 0, acc)
+            assert added == len(mine) + (1 if rank == 0 else 0)
+            for j, g in enumerate(mine):
+                assert np.array_equal(stats[1 + j]["warp"], full_stats[g]["warp"])
+                assert stats[1 + j]["iterations"] == full_stats[g]["iterations"]
+            total += acc
+            added_total += added
+        assert added_total == n
+        out = stacker.finalize_mean(total, added_total).cpu().numpy()
+        assert np.max(np.abs(out - full)) <= 1e-6

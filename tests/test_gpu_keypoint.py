@@ -197,3 +197,29 @@ def test_keypoint_match_lmeds_matches_oracle(stacker, kp_stack):
     assert np.max(np.abs(out - ref)) <= 4e-6
     with pytest.raises(NotImplementedYet):
         stacker.keypoint_match(list(frames[:2]), KeyPointMatchParameters(RHO, 5.0, 0.80, 0.9))
+
+
+def test_frame_sharded_ranks_reproduce_the_single_gpu_stack(stacker, kp_stack):
+    import torch
+    from libstacker_rs_amd.shard import shard_moving_frames
+    frames, _ = kp_stack
+    bad = np.full_like(frames[0], 128)                       # one frame that gets dropped, on the second rank
+    stack = np.stack([frames[0], frames[1], frames[2], bad, frames[3]])
+    n = len(stack)
+    d_full, full, full_stats = stacker.keypoint_match(list(stack), PARAMS, return_stats=True)
+    total = torch.zeros((stack.shape[1], stack.shape[2], 3), dtype=torch.float32, device="cuda")
+    added_total = dropped_total = 0
+    for rank in range(2):
+        mine = shard_moving_frames(n, 2, rank)
+        acc = torch.empty_like(total)
+        sub = torch.from_numpy(np.ascontiguousarray(stack[[0] + mine])).cuda()
+        added, dropped, stats = stacker.keypoint_match_shard(sub, PARAMS, rank == 0, acc)
+        for j, g in enumerate(mine):
+            assert stats[1 + j]["status"] == full_stats[g]["status"]
+            assert np.array_equal(stats[1 + j]["warp"], full_stats[g]["warp"])
+        total += acc
+        added_total += added
+        dropped_total += dropped
+    assert dropped_total == d_full == 1 and added_total == n - 1
+    out = stacker.finalize_mean(total, added_total).cpu().numpy()
+    assert np.max(np.abs(out - full)) <= 1e-6
