@@ -175,6 +175,12 @@ stk_status stk_grey(stk_ctx* ctx, const stk_frames* frame /* n==1 */, void* out)
 /* Mat::convert_to(CV_32F, alpha) utils.rs:133 (alpha = 1/255 there). */
 stk_status stk_convert_f32(stk_ctx* ctx, const stk_frames* frame /* n==1 */, double alpha,
                            float* out);
+/* sharpness_modified_laplacian / _variance_of_laplacian / _tenengrad(k_size) / _normalized_gray_level_variance
+ * (lib.rs:1030-1166; the pre-filter of examples/main.rs:40-47) of a single-channel 8-bit or f32 image, tightly packed.
+ * `ksize` is read by TENG only (1, 3, 5 or 7, else STK_INVALID_PARAMS like lib.rs:1105). */
+enum { STK_SHARPNESS_LAPM = 0, STK_SHARPNESS_LAPV = 1, STK_SHARPNESS_TENG = 2, STK_SHARPNESS_GLVN = 3 };
+stk_status stk_sharpness(stk_ctx* ctx, const void* grey, int32_t depth, int32_t width, int32_t height,
+                         int32_t location, int32_t metric, int32_t ksize, double* out);
 /* One frame's whole ECC preparation as ecc_match runs it per frame: cvt_color(BGR2GRAY) (utils.rs:136-142) followed
  * by findTransformECC's own GaussianBlur of the float image (lib.rs:769-777) in one fused pass. `out` is a tightly
  * packed width x height f32 plane in the frame's location. BGR frames, 8-bit or f32. */

@@ -71,6 +71,8 @@ SIGNATURES = {
     "stk_finalize_mean": (c_status, [C.c_void_p, C.POINTER(ImageF32), C.c_int64, C.POINTER(ImageF32)]),
     "stk_grey": (c_status, [C.c_void_p, C.POINTER(Frames), C.c_void_p]),
     "stk_convert_f32": (c_status, [C.c_void_p, C.POINTER(Frames), C.c_double, C.c_void_p]),
+    "stk_sharpness": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(C.c_double)]),
     "stk_grey_blur_f32": (c_status, [C.c_void_p, C.POINTER(Frames), C.c_int32, C.c_void_p]),
     "stk_gaussian_blur_f32": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_void_p]),

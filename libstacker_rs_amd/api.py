@@ -317,6 +317,32 @@ class Stacker:
         self._check(self._lib.stk_convert_f32(self._h, C.byref(m.c_frames), float(alpha), C.c_void_p(ptr)))
         return out
 
+    def _sharpness(self, grey, metric: int, ksize: int = 0) -> float:
+        g = np.ascontiguousarray(grey)
+        if g.ndim != 2 or str(g.dtype) not in ("uint8", "float32"):
+            raise InvalidParams("sharpness metrics take a single-channel uint8 or float32 image")
+        h, w = g.shape
+        out = C.c_double(0.0)
+        self._check(self._lib.stk_sharpness(self._h, C.c_void_p(g.ctypes.data), _DEPTH[str(g.dtype)], w, h, HOST,
+                                            int(metric), int(ksize), C.byref(out)))
+        return out.value
+
+    def sharpness_modified_laplacian(self, grey) -> float:
+        """lib.rs:1032-1071 (LAPM, Nayar89)."""
+        return self._sharpness(grey, 0)
+
+    def sharpness_variance_of_laplacian(self, grey) -> float:
+        """lib.rs:1075-1091 (LAPV, Pech2000)."""
+        return self._sharpness(grey, 1)
+
+    def sharpness_tenengrad(self, grey, k_size: int) -> float:
+        """lib.rs:1103-1147 (TENG, Krotkov86); k_size must be 1, 3, 5 or 7."""
+        return self._sharpness(grey, 2, k_size)
+
+    def sharpness_normalized_gray_level_variance(self, grey) -> float:
+        """lib.rs:1151-1166 (GLVN, Santos97)."""
+        return self._sharpness(grey, 3)
+
     def grey_blur_f32(self, frame, ksize: int):
         """cvt_color(BGR2GRAY) + findTransformECC's GaussianBlur of one frame, fused (the per-frame ECC preparation)."""
         m = _Marshalled([frame])

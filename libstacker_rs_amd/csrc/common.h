@@ -135,6 +135,8 @@ hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStr
 constexpr int ECC_TILE_W = 64, ECC_TILE_H = 16;
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
                             EccFrameResult* results, hipStream_t s);
+hipError_t launch_sharpness(const void* grey, int depth, int w, int h, int metric, int ksize, void* partials, int n_blocks,
+                            hipStream_t s);
 hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
                            const float* init_warps /* n_frames*9 or null */, hipStream_t s);
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s);

@@ -5,6 +5,7 @@
 // frame indices with one f32 accumulator per worker thread, this runtime keeps every frame of the
 // shard resident in HBM, runs the alignment of ALL frames as a device-side work queue and then
 // folds every warped frame into one accumulator in a single launch.
+#include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -613,6 +614,50 @@ stk_status stk_grey_blur_f32(stk_ctx* ctx, const stk_frames* f, int32_t ksize, f
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)f->width * 4, ctx->blur_tmp.p, (size_t)stride * 4, (size_t)f->width * 4, f->height,
                              f->location == STK_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+stk_status stk_sharpness(stk_ctx* ctx, const void* grey, int32_t depth, int32_t width, int32_t height, int32_t location,
+                         int32_t metric, int32_t ksize, double* out) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (!grey || !out || width <= 0 || height <= 0) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
+    if (depth != 8 && depth != 32) return fail(ctx, STK_INVALID_PARAMS, "sharpness input must be 8-bit or f32, single channel");
+    if (metric < STK_SHARPNESS_LAPM || metric > STK_SHARPNESS_GLVN) return fail(ctx, STK_INVALID_PARAMS, "unknown sharpness metric");
+    if (metric == STK_SHARPNESS_TENG && ksize != 1 && ksize != 3 && ksize != 5 && ksize != 7)
+        return fail(ctx, STK_INVALID_PARAMS, "Kernel size must be 1, 3, 5, or 7");                    // lib.rs:1105-1109
+    (void)hipSetDevice(ctx->device);
+    const size_t ib = (size_t)width * height * (depth / 8);
+    const void* src = grey;
+    if (location == STK_HOST) {
+        HIP_TRY(ctx->frames.reserve(ib));
+        HIP_TRY(hipMemcpyAsync(ctx->frames.p, grey, ib, hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->frames.p;
+    }
+    const int nb = (int)std::max<size_t>(1, std::min<size_t>(1024, ((size_t)width * height + 255) / 256));
+    HIP_TRY(ctx->scratch.reserve((size_t)nb * 16));
+    HIP_TRY(launch_sharpness(src, depth, width, height, metric, ksize, ctx->scratch.p, nb, ctx->stream));
+    std::vector<unsigned char> hostp((size_t)nb * 16);
+    HIP_TRY(hipMemcpyAsync(hostp.data(), ctx->scratch.p, hostp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // partials added in index order; 8-bit input: exact integers (LAPM carries a factor 4)
+    double s = 0, sq = 0;
+    if (depth == 8) {
+        const long long* p = reinterpret_cast<const long long*>(hostp.data());
+        long long is = 0, isq = 0;
+        for (int b = 0; b < nb; b++) { is += p[2 * b]; isq += p[2 * b + 1]; }
+        s = (double)is; sq = (double)isq;
+        if (metric == STK_SHARPNESS_LAPM) s *= 0.25;
+    } else {
+        const double* p = reinterpret_cast<const double*>(hostp.data());
+        for (int b = 0; b < nb; b++) { s += p[2 * b]; sq += p[2 * b + 1]; }
+    }
+    const double scale = 1. / ((double)width * height);          // cv::mean / meanStdDev multiply by the reciprocal
+    if (metric == STK_SHARPNESS_LAPM || metric == STK_SHARPNESS_TENG) *out = s * scale;
+    else {
+        const double mean = s * scale;
+        const double sigma = std::sqrt(std::max(sq * scale - mean * mean, 0.));
+        *out = metric == STK_SHARPNESS_LAPV ? sigma * sigma : (sigma * sigma) / std::max(mean, DBL_EPSILON);
+    }
     return STK_OK;
 }
 

@@ -250,3 +250,13 @@ def resize_area_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     if rc:
         raise ValueError("orc_resize_area_u8 rc=%d" % rc)
     return out
+
+
+def sharpness(grey, metric: int, ksize: int = 0) -> float:
+    """The reference's sharpness metrics (lib.rs:1030-1166): 0 LAPM, 1 LAPV, 2 TENG(ksize), 3 GLVN."""
+    g = np.ascontiguousarray(grey)
+    out = C.c_double(0.0)
+    rc = lib().orc_sharpness(_p(g), _depth(g), g.shape[1], g.shape[0], int(metric), int(ksize), C.byref(out))
+    if rc:
+        raise ValueError("orc_sharpness rc=%d" % rc)
+    return out.value

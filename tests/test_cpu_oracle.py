@@ -213,3 +213,25 @@ def test_find_homography_exact_and_ransac():
     assert abs(H[2, 2] - 1) < 1e-12
     with pytest.raises(ValueError):
         oracle.find_homography(src[:3], dst[:3], 8, 3.0)
+
+
+def test_sharpness_known_answers():
+    # constant image: every derivative filter gives 0, variance 0
+    flat = np.full((20, 30), 77, np.uint8)
+    assert [oracle.sharpness(flat, m, 3) for m in range(4)] == [0.0, 0.0, 0.0, 0.0]
+    # GLVN of a half 0 / half 100 image: mean 50, variance 2500 -> 50
+    half = np.zeros((10, 10), np.uint8); half[:, 5:] = 100
+    assert oracle.sharpness(half, 3) == 50.0
+    # horizontal ramp p = 3x: Sobel(3) gx = 8 * 3 = 24 in the interior and 0 on the two reflected border columns,
+    # gy = 0 -> TENG = 24^2 * (w - 2) / w ; the second derivative is 0 inside, |(-1)(3) + 2(0) - 3| = 6 at x = 0
+    # (and the same at x = w-1 by symmetry) -> LAPM = 12 / w
+    w, h = 16, 9
+    ramp = np.tile((3 * np.arange(w)).astype(np.uint8), (h, 1))
+    assert oracle.sharpness(ramp, 2, 3) == 24.0 ** 2 * (w - 2) / w
+    assert oracle.sharpness(ramp, 0) == pytest.approx(12.0 / w, rel=0, abs=1e-15)
+    # single bright pixel (value 8) in a 5x5 zero image, Laplacian(ksize 3) kernel [2 0 2; 0 -8 0; 2 0 2]:
+    # values -64 at the pixel, 16 at the four diagonal neighbours -> mean = 0, E[v^2] = (4096 + 4 * 256) / 25
+    dot = np.zeros((5, 5), np.uint8); dot[2, 2] = 8
+    assert oracle.sharpness(dot, 1) == pytest.approx((4096 + 1024) / 25.0, rel=1e-15)
+    with pytest.raises(ValueError):
+        oracle.sharpness(flat, 2, 2)
