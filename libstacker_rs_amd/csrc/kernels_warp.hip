@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
     if (a.accumulate) { s0 = accp[0]; s1 = accp[1]; s2 = accp[2]; }
     const float fx = (float)x, fy = (float)y;
     const int sw = a.sw, sh = a.sh;
-    const size_t stride = a.src_stride;
+    const int stride32 = (int)a.src_stride;
     const float alpha = a.alpha, b0 = a.bv[0], b1 = a.bv[1], b2 = a.bv[2];
 
     for (int f0 = 0; f0 < a.n_frames; f0 += WU) {
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
         int ox[WU];            // ix - xb: 0 normal, -1 left tap outside, 1 right tap outside, else both outside
         bool vy0[WU], vy1[WU];
         int sh0[WU], sh1[WU];  // right-shift (bits) that undoes the end-of-buffer back-off
+        bool interior = true;
 #pragma unroll
         for (int u = 0; u < WU; u++) {
             const int f = min(f0 + u, a.n_frames - 1);
@@ -182,8 +183,29 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
             const int back0 = (yb0 == sh - 1 && xb == sw - 2) ? 2 : 0;
             const int back1 = (yb1 == sh - 1 && xb == sw - 2) ? 2 : 0;
             sh0[u] = back0 * 8; sh1[u] = back1 * 8;
-            raw0[u] = load_u64_unaligned(src + (size_t)yb0 * stride + (size_t)xb * 3 - back0);
-            raw1[u] = load_u64_unaligned(src + (size_t)yb1 * stride + (size_t)xb * 3 - back1);
+            // one frame is < 4 GiB (checked by the launcher): 32-bit offsets on the frame's uniform base pointer
+            raw0[u] = load_u64_unaligned(src + (unsigned)(yb0 * stride32 + xb * 3 - back0));
+            raw1[u] = load_u64_unaligned(src + (unsigned)(yb1 * stride32 + xb * 3 - back1));
+            // all four taps inside the frame and no end-of-buffer back-off: the common case, decided per wave below
+            interior &= (ix == xb) & ((unsigned)iy < (unsigned)(sh - 1)) & ((back0 | back1) == 0);
+        }
+#define STK_CH(d, sft) ((float)(((d) >> (sft)) & 0xffu) * alpha)
+#define STK_LERP(p00, p01, p10, p11)                                                   \
+    __builtin_fmaf(ay[u], __builtin_fmaf(ax[u], (p11) - (p10), (p10)) - __builtin_fmaf(ax[u], (p01) - (p00), (p00)), \
+                   __builtin_fmaf(ax[u], (p01) - (p00), (p00)))
+        if (__all(interior)) {
+            // every lane of the wave has all taps of all WU frames inside: same arithmetic without the border selects
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                if (f0 + u < a.n_frames) {
+                    const uint32_t a0 = (uint32_t)raw0[u], a1 = (uint32_t)(raw0[u] >> 24);
+                    const uint32_t c0 = (uint32_t)raw1[u], c1 = (uint32_t)(raw1[u] >> 24);
+                    s0 = s0 + STK_LERP(STK_CH(a0, 0), STK_CH(a1, 0), STK_CH(c0, 0), STK_CH(c1, 0));
+                    s1 = s1 + STK_LERP(STK_CH(a0, 8), STK_CH(a1, 8), STK_CH(c0, 8), STK_CH(c1, 8));
+                    s2 = s2 + STK_LERP(STK_CH(a0, 16), STK_CH(a1, 16), STK_CH(c0, 16), STK_CH(c1, 16));
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int u = 0; u < WU; u++) {
@@ -197,10 +219,6 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
                 const uint32_t tl0 = ox[u] == 0 ? a0 : a1, tr0 = ox[u] == 0 ? a1 : a0;
                 const uint32_t tl1 = ox[u] == 0 ? c0 : c1, tr1 = ox[u] == 0 ? c1 : c0;
                 const bool v00 = l_ok & vy0[u], v01 = r_ok & vy0[u], v10 = l_ok & vy1[u], v11 = r_ok & vy1[u];
-#define STK_CH(d, sft) ((float)(((d) >> (sft)) & 0xffu) * alpha)
-#define STK_LERP(p00, p01, p10, p11)                                                   \
-    __builtin_fmaf(ay[u], __builtin_fmaf(ax[u], (p11) - (p10), (p10)) - __builtin_fmaf(ax[u], (p01) - (p00), (p00)), \
-                   __builtin_fmaf(ax[u], (p01) - (p00), (p00)))
                 {
                     const float p00 = v00 ? STK_CH(tl0, 0) : b0, p01 = v01 ? STK_CH(tr0, 0) : b0;
                     const float p10 = v10 ? STK_CH(tl1, 0) : b0, p11 = v11 ? STK_CH(tr1, 0) : b0;
@@ -216,10 +234,10 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
                     const float p10 = v10 ? STK_CH(tl1, 16) : b2, p11 = v11 ? STK_CH(tr1, 16) : b2;
                     s2 = s2 + STK_LERP(p00, p01, p10, p11);
                 }
-#undef STK_CH
-#undef STK_LERP
             }
         }
+#undef STK_CH
+#undef STK_LERP
     }
     accp[0] = s0; accp[1] = s1; accp[2] = s2;
 }
@@ -227,7 +245,7 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
     dim3 grid((a.dw + 63) / 64, (a.dh + 3) / 4);
     if (depth == 8 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 &&
-        (size_t)a.sw * a.sh * 3 >= 16) {
+        (size_t)a.sw * a.sh * 3 >= 16 && a.src_stride * (size_t)a.sh < ((size_t)1 << 31)) {
         if (a.is_affine) warp_accumulate_u8c3_kernel<true><<<grid, 256, 0, s>>>(a);
         else warp_accumulate_u8c3_kernel<false><<<grid, 256, 0, s>>>(a);
         return hipGetLastError();
