@@ -53,7 +53,8 @@ def main() -> None:
                     help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the reduce goes through gloo/CPU "
                          "(checks the sharded code path, not a performance number)")
     ap.add_argument("--profile-launches", type=int, default=1,
-                    help="1: bracket every ECC iteration launch with HIP events (roofline.achieved); 0: off")
+                    help="0: no per-launch timing; 1: HIP event pairs around every 3rd ECC iteration launch (roofline.achieved); "
+                         "n > 1: around every n-th")
     args = ap.parse_args()
 
     import numpy as np
@@ -102,13 +103,16 @@ def main() -> None:
         k, v = kv.split("=")
         st.set_option(k, int(v))
     st.set_option("profile", 2 if args.profile_launches else 1)
+    # an event pair around a launch keeps it from being dispatched back to back with its neighbours: bracketing every
+    # launch costs ~5 % of `value`, so every 3rd launch is sampled (3 is coprime with the 4-launch polling chunk)
+    st.set_option("profile_stride", max(1, args.profile_launches if args.profile_launches > 1 else 3))
     ecc_params = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
     kp_params = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
     acc = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     out = torch.empty_like(acc)
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
 
-    agg = {"ecc_iter_ms": 0.0, "ecc_iter_timed": 0, "ecc_slot_iterations": 0, "prep_ms": 0.0, "align_ms": 0.0,
+    agg = {"ecc_iter_ms": 0.0, "ecc_iter_timed": 0, "ecc_iter_launches": 0, "ecc_slot_iterations": 0, "prep_ms": 0.0, "align_ms": 0.0,
            "warp_ms": 0.0, "warp_frames": 0, "warp_launches": 0}
     last_stats = None
 
@@ -179,9 +183,9 @@ def main() -> None:
             # ECC iteration kernel: ALGORITHMIC bytes = 16 B/px per frame-iteration (template 4 B +
             # frame-0 image/gx/gy 12 B); one launch advances `slots` frames by one iteration.
             alg_bytes_total = 16.0 * px * agg["ecc_slot_iterations"]
-            launches = agg["ecc_iter_timed"]
-            avg_ms = agg["ecc_iter_ms"] / launches
-            achieved = alg_bytes_total / (agg["ecc_iter_ms"] * 1e-3) / 1e9
+            launches = agg["ecc_iter_launches"]                     # every launch of the timed region (incl. drained no-ops)
+            avg_ms = agg["ecc_iter_ms"] / agg["ecc_iter_timed"]     # event-timed sample: every 3rd of them
+            achieved = (alg_bytes_total / launches) / (avg_ms * 1e-3) / 1e9
             # HBM-side traffic per launch from the PMC passes of the SAME command (tools/profile_round.sh,
             # separate FETCH_SIZE / WRITE_SIZE passes; summary committed under profiles/): FETCH_SIZE is
             # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 (the float4 scale_kernel in the same
@@ -197,7 +201,7 @@ def main() -> None:
             res["roofline"] = {"kernel": "ecc_iter_h8_kernel (ECC iteration pass, homography)", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "traffic_source": "rocprofv3 --pmc (profiles/r01/pmc_summary.json)" if traffic else None,
-                               "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                               "avg_launch_ms": round(avg_ms, 5), "launches": launches, "launches_timed": agg["ecc_iter_timed"],
                                "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
         its = [s["iterations"] for s in (last_stats or [])[1:]]
         src_b = 3 * px

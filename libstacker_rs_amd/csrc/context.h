@@ -31,6 +31,7 @@ struct stk_ctx {
     int opt_subpixel_bits = 0;
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
+    int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
     int opt_kp_workers = 8;       // host threads (each with its own stream and ORB workspace) of the keypoint path
     int opt_ecc_fused = 0;        // variants 0/3: run the solve step in extra workgroups of the other slot group's pixel pass (two
                                   // alternating slot groups). Off by default: with 32 frames per GPU the longer end-of-stack tail

@@ -127,6 +127,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
     else if (n == "ecc_variant") { if (value < 0 || value > 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0..3"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "ecc_fused") ctx->opt_ecc_fused = value != 0;
+    else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
@@ -286,7 +287,11 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                     merged = true;
                 }
                 for (int c = 0; c < chunk; c++) {
-                    const bool timed = ctx->opt_profile >= 2 && prof_used + 2 <= ctx->prof_ev.size();
+                    // per-launch timing (profile >= 2) brackets every `profile_stride`-th pixel pass with an event pair: an
+                    // event between two kernels keeps them from being dispatched back to back (~5 % of the step if every
+                    // launch is bracketed), so bench.py samples
+                    const bool timed = ctx->opt_profile >= 2 && prof_used + 2 <= ctx->prof_ev.size() &&
+                                       (ctx->timing.ecc_iter_launches + c) % ctx->opt_profile_stride == 0;
                     if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used], ctx->stream));
                     if (fused && !merged) {
                         // launch n iterates group n % 2 and, in its last-region workgroups, solves the other group's previous pass
