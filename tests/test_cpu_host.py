@@ -114,3 +114,19 @@ def test_synthetic_generator_is_seeded_and_sharded_consistently():
     assert synth.corner_error(np.eye(3), np.eye(3), 96, 64) == 0
     u16, _ = synth.make_stack(1, 32, 24, depth=16)
     assert u16.numpy().dtype == np.uint16
+
+
+def test_orb_bit_pattern_is_pinned():
+    """ORB's 256 BRIEF test pairs (OpenCV `bit_pattern_31_`): pinned by hash, and row by row against scikit-image's
+    verbatim copy of the OpenCV table where that package happens to be installed (it is in the build container)."""
+    import hashlib
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "libstacker_rs_amd", "csrc", "orb_pattern.h")).read()
+    body = txt[txt.index("{", txt.index("ORB_BIT_PATTERN_31")) + 1: txt.rindex("}")]
+    table = np.array([int(v) for v in re.findall(r"-?\d+", body)], dtype=np.int8)
+    assert table.size == 1024 and np.abs(table).max() <= 13          # 31x31 patch, rotated radius <= 15*sqrt(2)/... fits
+    assert hashlib.sha256(table.tobytes()).hexdigest() == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    sk = "/opt/conda/lib/python3.9/site-packages/skimage/feature/orb_descriptor_positions.txt"
+    if os.path.exists(sk):
+        assert np.array_equal(np.loadtxt(sk).astype(np.int8).reshape(-1), table)
