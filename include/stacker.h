@@ -130,9 +130,18 @@ const char* stk_last_error(const stk_ctx* ctx);    /* valid until the next call 
  * restores the context's own stream. */
 stk_status  stk_set_stream(stk_ctx* ctx, void* hip_stream);
 stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
-/* Tuning knobs (do not change results): "ecc_slots" (frames iterated
- * concurrently), "warp_subpixel_bits" (0 = exact f32 coordinates, OpenCV>=4.11
- * kernels; 5 = classic 1/32-px quantised table), "profile" (per-stage events). */
+/* Tuning knobs. None changes a frame's warp or the stacked image except where noted:
+ *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto from the frame size)
+ *   "ecc_blocks"         workgroups per ECC launch (default 1152); changes the f32 summation partition, i.e. results
+ *                        at round-off level (within the stated ECC tolerance)
+ *   "ecc_variant"        ECC pixel-pass kernel: 3 row-factorised (default), 0 direct, 1 LDS-tiled, 2 row-sharing
+ *   "ecc_fused"          1: two alternating slot groups with the solve hidden inside the other group's pass
+ *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
+ *   "kp_workers"         host threads of the keypoint path (each with its own stream and ORB workspace)
+ *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table
+ *                        (changes results: it selects the other OpenCV behaviour)
+ *   "profile"            0 off, 1 per-stage events (stk_get_timing), 2 + event pairs around ECC launches
+ *   "profile_stride"     with profile = 2: bracket every n-th ECC launch only */
 stk_status  stk_set_option(stk_ctx* ctx, const char* name, int64_t value);
 const char* stk_version(void);
 
