@@ -131,7 +131,8 @@ const char* stk_last_error(const stk_ctx* ctx);    /* valid until the next call 
 stk_status  stk_set_stream(stk_ctx* ctx, void* hip_stream);
 stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
 /* Tuning knobs. None changes a frame's warp or the stacked image except where noted:
- *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto from the frame size)
+ *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto from the frame size); on large
+ *                        frames it sets the workgroups per frame, see "ecc_blocks"
  *   "ecc_blocks"         workgroups per ECC launch (default 1152); changes the f32 summation partition, i.e. results
  *                        at round-off level (within the stated ECC tolerance)
  *   "ecc_variant"        ECC pixel-pass kernel: 3 row-factorised (default), 0 direct, 1 LDS-tiled, 2 row-sharing
