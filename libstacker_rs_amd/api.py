@@ -110,6 +110,19 @@ def _is_torch(x) -> bool:
 _DEPTH = {"uint8": 8, "uint16": 16, "float32": 32}
 
 
+# Device tensors handed to the engine must be complete on the engine's stream. Unless a Stacker has been bound to
+# torch's current stream (use_torch_stream), work queued on torch's stream (an index op, a clone, an in-place add that
+# produced the tensor) is drained before the pointers cross the C ABI.
+_BOUND_TO_TORCH_STREAM = False
+
+
+def _torch_inputs_ready():
+    if not _BOUND_TO_TORCH_STREAM:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+
+
 class _Marshalled:
     """Pointers + geometry of a frame stack, keeping the owners alive."""
 
@@ -161,6 +174,8 @@ class _Marshalled:
         self.ptr_arr = (C.c_void_p * max(self.n, 1))(*ptrs)
         self.c_frames = _ffi.Frames(C.cast(self.ptr_arr, C.POINTER(C.c_void_p)), self.n, self.w, self.h, self.c,
                                     self.depth, self.location, 0)
+        if self.location == DEVICE:
+            _torch_inputs_ready()
 
 
 class Stacker:
@@ -199,8 +214,10 @@ class Stacker:
         self._check(self._lib.stk_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
     def use_torch_stream(self):
+        global _BOUND_TO_TORCH_STREAM
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        _BOUND_TO_TORCH_STREAM = True
 
     def timing(self) -> dict:
         t = _ffi.Timing()
@@ -285,6 +302,7 @@ class Stacker:
 
     def finalize_mean(self, sum_img, n_frames: int, out=None):
         """img / n  (lib.rs:339-345, 836-839) on a cuda tensor; in place when out is None."""
+        _torch_inputs_ready()
         h, w, c = sum_img.shape
         out = sum_img if out is None else out
         a = _ffi.ImageF32(sum_img.data_ptr(), w, h, c, DEVICE, 0)
