@@ -136,7 +136,6 @@ stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
  *   "ecc_blocks"         workgroups per ECC launch (default 1152); changes the f32 summation partition, i.e. results
  *                        at round-off level (within the stated ECC tolerance)
  *   "ecc_variant"        ECC pixel-pass kernel: 3 row-factorised (default), 0 direct, 1 LDS-tiled, 2 row-sharing
- *   "ecc_fused"          1: two alternating slot groups with the solve hidden inside the other group's pass
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
  *   "kp_workers"         host threads of the keypoint path (each with its own stream and ORB workspace)
  *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table

@@ -86,17 +86,7 @@ struct EccIterArgs {
     double* partials;            // [all slots][nsums][nb]
     double* sums;                // [all slots][ECC_MAX_SUMS]: the reduced sums, stage 1 -> stage 2 of the solve kernel
     int* tickets;                // [all slots]: arrival counter of the solve kernel's stage-1 workgroups (self-resetting)
-    // fused launches (variants 0 and 3): the slots are split in two groups that alternate; while one group's
-    // pixel pass runs, workgroups of that launch first solve the OTHER group's previous pass (its partials are
-    // complete: they were written by the previous launch), so the solve latency is hidden (kernels_ecc.hip).
-    int slot0;
-    int solve_slot0, solve_n;
-    int solve_first;             // 1: the first regions' workgroups solve (oversubscribed grid), 0: the last regions'
-    int motion;
-    EccCriteria crit;
-    EccQueue* queue;
-    EccFrameResult* results;
-    const float* init_warps;
+    int slot0;                   // first slot of this launch (0: all slots in one launch)
 };
 
 struct WarpFrame {

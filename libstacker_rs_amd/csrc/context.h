@@ -33,10 +33,6 @@ struct stk_ctx {
     int opt_ecc_chunk = 4;
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
     int opt_kp_workers = 8;       // host threads (each with its own stream and ORB workspace) of the keypoint path
-    int opt_ecc_fused = 0;        // variants 0/3: two alternating slot groups, the solve of one group done by workgroups of the other
-                                  // group's pixel pass (kernels_ecc.hip: fused_solve_duty). Off by default: with 32 frames per GPU
-                                  // the longer end-of-stack tail of 8 frames in flight cancels the hidden solve (r01: 2.62k vs 2.80k
-                                  // frames/s); on long stacks it is worth ~8 %
     int opt_ecc_blocks = 1152;    // total workgroups of one ECC iteration launch (all slots): more than the 768 the chip holds at
                                   // once, so the dispatcher balances the uneven rows-per-wave split (960 / 1344 measure worse)
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = row-factorised Hessian (homography, default), 0 = direct gathers,

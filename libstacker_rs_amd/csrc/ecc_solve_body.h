@@ -1,6 +1,7 @@
 // ecc_solve_body.h — the per-iteration "solve" step of findTransformECC as a device routine (see
-// kernels_ecc_solve.hip for the description). Shared by the stand-alone solve kernel and the fused
-// iteration kernels, which run it in a few extra workgroups next to the next group's pixel pass.
+// kernels_ecc_solve.hip for the description): the normal equations, the parameter update and the loop control of
+// one slot, run by one workgroup. (A variant that ran it inside the other slot group's pixel pass was measured in
+// round 1 and removed: no gain at 32 or 256 frames per GPU)
 #pragma once
 #include "common.h"
 
@@ -48,8 +49,8 @@ __device__ inline void invert_small_f32(const float* S, int n, float* D) {
     } else { for (int i = 0; i < 9; i++) D[i] = 0; }
 }
 
-// One workgroup of SOLVE_WAVES wavefronts solves one slot. Called by the stand-alone solve kernel (16 waves)
-// and, with 4 waves, by the extra workgroups of the fused iteration kernels (kernels_ecc.hip).
+// One workgroup of SOLVE_WAVES wavefronts solves one slot. PRE_REDUCED: the block partials were already reduced to
+// the 66 sums by the caller's stage 1 (kernels_ecc_solve.hip); otherwise this workgroup reduces them itself.
 template <int SOLVE_WAVES, bool PRE_REDUCED = false>
 __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, int motion, EccCriteria crit, EccQueue* queue,
                                                EccFrameResult* results, const float* init_warps) {

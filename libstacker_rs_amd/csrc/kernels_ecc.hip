@@ -24,7 +24,6 @@
 //  blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD and
 //  its L2: the frame-0 planes they all read are fetched from HBM/MALL once per XCD.
 #include "common.h"
-#include "ecc_solve_body.h"
 
 namespace stk {
 
@@ -202,22 +201,6 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NS], const EccIt
     }
 }
 
-// Fused schedule: two slot groups alternate; while this launch runs the pixel pass of one group, the OTHER
-// group's previous pass is solved by workgroups of this launch — not extra ones, but workgroups that also own
-// template rows. Which ones depends on the grid (a.solve_first):
-//  * more workgroups than the chip holds at once (default, 1152 on 256 CUs x 3): the FIRST regions, which are
-//    dispatched at t = 0 — the solve is over long before the launch ends and the hardware dispatcher balances the rest;
-//  * exactly one resident wave of workgroups: the LAST regions, which own the fewest template rows (rows are dealt
-//    round-robin: with 2160 rows over 768 waves they have 2 rows where the first have 3) — the solve fits their slack.
-// Done before the idle-slot check: an idle slot's workgroups still serve.
-__device__ __forceinline__ void fused_solve_duty(const EccIterArgs& a, int slot, int region) {
-    if (a.solve_n <= 0) return;
-    const int r = a.solve_first ? region : a.nb - 1 - region;
-    const int duty = r * a.n_slots + (slot - a.slot0);
-    if (duty < a.solve_n)
-        ecc_solve_body<4>(a, a.solve_slot0 + duty, a.motion, a.crit, a.queue, a.results, a.init_warps);
-}
-
 __device__ __forceinline__ void load_slot_const(const EccSlot* sl, const EccIterArgs& a, SlotConst& c) {
     c.m0 = sl->warp[0]; c.m1 = sl->warp[1]; c.m2 = sl->warp[2];
     c.m3 = sl->warp[3]; c.m4 = sl->warp[4]; c.m5 = sl->warp[5];
@@ -241,7 +224,6 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
     const int xcd = bid & 7, q = bid >> 3;
     const int slot = a.slot0 + q % a.n_slots;
     const int region = (q / a.n_slots) * 8 + xcd;
-    fused_solve_duty(a, slot, region);
     const EccSlot* sl = a.slots + slot;
     const int frame = sl->frame;
     if (frame < 0) return;                                    // idle slot: whole block leaves
@@ -319,7 +301,6 @@ __global__ __launch_bounds__(256, 3) void ecc_iter_h8_kernel(EccIterArgs a) {   
     const int xcd = bid & 7, q = bid >> 3;
     const int slot = a.slot0 + q % a.n_slots;
     const int region = (q / a.n_slots) * 8 + xcd;
-    fused_solve_duty(a, slot, region);
     const EccSlot* sl = a.slots + slot;
     const int frame = sl->frame;
     if (frame < 0) return;
@@ -679,7 +660,6 @@ __global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
 
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
-    // variants 0 and 3: a.solve_n > 0 = fused solve of the other slot group inside this launch (fused_solve_duty)
     if (variant == 3 && motion == STK_MOTION_HOMOGRAPHY) {   // other motions: direct variant below
         if (grid <= 0) return hipSuccess;
         ecc_iter_h8_kernel<<<grid, 256, 0, s>>>(a);

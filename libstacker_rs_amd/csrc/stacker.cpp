@@ -126,7 +126,6 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
     else if (n == "ecc_variant") { if (value < 0 || value > 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0..3"); ctx->opt_ecc_variant = (int)value; }
-    else if (n == "ecc_fused") ctx->opt_ecc_fused = value != 0;
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
@@ -148,7 +147,6 @@ struct EccPlan {
     int ref_stride;
     size_t ref_plane_floats;
     int n_slots, nb, nsums;
-    int group_a, group_b;   // fused launches: slots [0, group_a) and [group_a, n_slots) alternate; 0/0 = not fused
 };
 
 static stk_status ecc_validate(stk_ctx* ctx, const stk_ecc_params* p, EccCriteria& crit) {
@@ -181,20 +179,8 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
         slots = (int)std::lround(4.0 * 8294400.0 / px);
         slots = std::max(4, std::min(slots, 16));
     }
-    // Fused launches (variants 0 and 3): two groups of `slots` slots alternate, the solve of one group runs in
-    // extra workgroups of the other group's pixel pass.
-    // (only when there are more frames than one group holds; a short stack iterates all its frames in one launch)
-    const bool fused = (ctx->opt_ecc_variant == 0 || ctx->opt_ecc_variant == 3) && ctx->opt_ecc_fused && n_templates > slots;
-    pl.group_a = pl.group_b = 0;
-    if (fused) {
-        const int total = std::max(1, std::min(2 * slots, std::max(n_templates, 1)));
-        pl.group_a = (total + 1) / 2; pl.group_b = total / 2;
-        pl.n_slots = total;
-        slots = pl.group_a;
-    } else {
-        pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
-        slots = pl.n_slots;
-    }
+    pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
+    slots = pl.n_slots;
     // blocks per slot: multiple of 8 (XCD-aware decode), each block = 4 waves = 4 rows per sweep
     // work units of one slot: 4-row groups (direct variant) or 64x16 tiles (tiled variant)
     const int units = ctx->opt_ecc_variant == 1 ? ((w + ECC_TILE_W - 1) / ECC_TILE_W) * ((h + ECC_TILE_H - 1) / ECC_TILE_H) : (h + 3) / 4;
@@ -251,11 +237,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     a.tickets = reinterpret_cast<int*>(a.sums + (size_t)pl.n_slots * ECC_MAX_SUMS);
     EccQueue* q = ctx->queue.as<EccQueue>();
     EccFrameResult* r = ctx->results.as<EccFrameResult>();
-    a.slot0 = 0; a.solve_slot0 = 0; a.solve_n = 0;
-    a.solve_first = pl.nb * std::max(pl.group_a, 1) > 768;   // 256 CUs x 3 resident workgroups of the pixel pass
-    a.motion = pl.motion; a.crit = crit; a.queue = q; a.results = r; a.init_warps = nullptr;
-    const bool fused = pl.group_a > 0;
-    long long fused_n = 0;                                  // launches issued so far (selects the group)
+    a.slot0 = 0;
     HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, a.tickets, q, pl.n_templates, r, init_warps_dev, ctx->stream));
     if (crit.n_iter >= 1) {
         // Enqueue chunks of (iterate, solve) launches; keep two chunks in flight and poll the
@@ -271,21 +253,8 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
             for (auto& e : ctx->prof_ev) HIP_TRY(hipEventCreate(&e));
         }
         ctx->host_done[0] = ctx->host_done[1] = 0;
-        int seen_done = 0;                                  // latest polled value of the device-side completion counter
-        bool merged = false;
         while (!done) {
             while (inflight < 2) {
-                if (fused && !merged && fused_n > 0 && seen_done >= pl.n_templates - pl.group_a) {
-                    // Tail of the stack: every unfinished frame already sits in a slot and there are no more than one
-                    // group's worth of them. Alternating two mostly idle groups would cost a launch per group and
-                    // iteration, so close the pipeline (solve the group whose pass is still open) and continue with
-                    // all slots in one launch + one solve, as the unfused schedule does.
-                    const bool gb = ((fused_n - 1) & 1) != 0;
-                    a.slot0 = gb ? pl.group_a : 0; a.n_slots = gb ? pl.group_b : pl.group_a; a.solve_n = 0;
-                    HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
-                    a.slot0 = 0; a.n_slots = pl.n_slots; a.solve_slot0 = 0;
-                    merged = true;
-                }
                 for (int c = 0; c < chunk; c++) {
                     // per-launch timing (profile >= 2) brackets every `profile_stride`-th pixel pass with an event pair: an
                     // event between two kernels keeps them from being dispatched back to back (~5 % of the step if every
@@ -293,17 +262,9 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                     const bool timed = ctx->opt_profile >= 2 && prof_used + 2 <= ctx->prof_ev.size() &&
                                        (ctx->timing.ecc_iter_launches + c) % ctx->opt_profile_stride == 0;
                     if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used], ctx->stream));
-                    if (fused && !merged) {
-                        // launch n iterates group n % 2 and, in its last-region workgroups, solves the other group's previous pass
-                        const bool gb = (fused_n & 1) != 0;
-                        a.slot0 = gb ? pl.group_a : 0; a.n_slots = gb ? pl.group_b : pl.group_a;
-                        a.solve_slot0 = gb ? 0 : pl.group_a;
-                        a.solve_n = fused_n == 0 ? 0 : (gb ? pl.group_a : pl.group_b);
-                        fused_n++;
-                    }
                     HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->opt_ecc_variant, ctx->stream));
                     if (timed) { HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used + 1], ctx->stream)); prof_used += 2; }
-                    if (!fused || merged) HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
+                    HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
                 }
                 launched += chunk;
                 ctx->timing.ecc_iter_launches += chunk;
@@ -313,8 +274,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                 inflight++;
             }
             HIP_TRY(hipEventSynchronize(ctx->poll_ev[head]));
-            seen_done = ctx->host_done[head];
-            if (seen_done >= pl.n_templates) done = true;
+            if (ctx->host_done[head] >= pl.n_templates) done = true;
             head ^= 1; inflight--;
             if (!done && launched > max_launches)
                 return fail(ctx, STK_PROCESSING_ERROR, "ECC queue did not drain (internal error)");
