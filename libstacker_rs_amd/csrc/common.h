@@ -16,8 +16,8 @@ namespace stk {
 //
 //  * frames          interleaved BGR u8/u16/f32 as handed in (OpenCV Mat layout).
 //  * reference planes (ECC "input" = frame 0, shared by every frame of the stack):
-//        three f32 planes  I (blurred grey), gx, gy  each (H+4) x ref_stride with a 2-pixel ZERO
-//        border on every side, so a bilinear footprint with BORDER_CONSTANT 0 is four
+//        f32 planes  I (blurred grey), gx, gy  and an interleaved (gx, gy) copy, each (H + 2 REF_PAD) x ref_stride
+//        with a REF_PAD-pixel ZERO border on every side, so a bilinear footprint with BORDER_CONSTANT 0 is
 //        unconditional loads after clamping the integer coordinate to [-2, W] x [-2, H].
 //  * templates       one blurred-grey f32 plane per moving frame, row stride rounded up to a
 //        multiple of 4 floats so each lane streams aligned 16-byte quads.
