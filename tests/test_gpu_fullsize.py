@@ -98,3 +98,48 @@ def test_keypoint_1080p_oracle_and_ground_truth(stacker):
     finally:
         stacker.set_option("kp_workers", 8)
     assert d1 == 0 and torch.equal(out, out1)
+
+
+def _jpeg_roundtrip(frames_u8):
+    """JPEG-encode/decode (quality 90) with the Pillow of the image's conda interpreter, if there is one: the reference's
+    inputs are camera JPEGs (BASELINE configs[0]); returns None where that interpreter is absent."""
+    import os
+    import subprocess
+    import tempfile
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, "in.npy"), os.path.join(d, "out.npy")
+        np.save(src, frames_u8)
+        code = ("import io, sys, numpy as np\nfrom PIL import Image\na = np.load(sys.argv[1])\nout = []\n"
+                "for f in a:\n    b = io.BytesIO(); Image.fromarray(f[..., ::-1]).save(b, format='JPEG', quality=90)\n"
+                "    out.append(np.asarray(Image.open(io.BytesIO(b.getvalue())))[..., ::-1])\n"
+                "np.save(sys.argv[2], np.stack(out))\n")
+        r = subprocess.run([py, "-c", code, src, dst], capture_output=True, timeout=120)
+        if r.returncode != 0 or not os.path.exists(dst):
+            return None
+        return np.ascontiguousarray(np.load(dst))
+
+
+def test_config0_nine_800x600_frames_keypoint_match(stacker):
+    # BASELINE configs[0]: the image_stacking_py set (9 JPEGs of about 800x600) is not in the container; SURVEY 8d
+    # substitutes 9 synthetic frames of that size, JPEG round-tripped where a Pillow is available
+    frames, G = synth.make_stack(9, 800, 600)
+    fr = frames.numpy()
+    jp = _jpeg_roundtrip(fr)
+    if jp is not None:
+        assert jp.shape == fr.shape and np.abs(jp.astype(int) - fr.astype(int)).mean() < 6    # JPEG noise, same content
+        fr = jp
+    dropped, out, stats = stacker.keypoint_match(list(fr), KP, return_stats=True)
+    d_o, ref, Hs, status = oracle.keypoint_match(list(fr), details=True)
+    assert dropped == d_o == 0
+    for i in range(1, 9):
+        assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-10)
+        assert synth.corner_error(stats[i]["warp"], G[i], 800, 600) <= (1.5 if jp is not None else 1.0)
+    assert np.max(np.abs(out - ref)) <= 9e-6                       # <= 1e-6 per folded frame
+    assert np.max(np.abs(out - ref)) <= 1e-4 * np.max(np.abs(ref))  # north-star tolerance
+    e_out = stacker.ecc_match(list(fr), ECC)
+    e_ref, warps, iters = oracle.ecc_match(list(fr), max_count=5000, epsilon=1e-5, gauss_filt_size=5)
+    rel = np.abs(e_out - e_ref) / np.maximum(np.abs(e_ref), 1e-3)
+    assert np.percentile(rel[4:-4, 4:-4], 99.5) < 4e-3
