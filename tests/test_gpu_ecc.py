@@ -207,3 +207,20 @@ def test_frame_sharded_ranks_reproduce_the_single_gpu_stack(stacker, small_stack
         assert added_total == n
         out = stacker.finalize_mean(total, added_total).cpu().numpy()
         assert np.max(np.abs(out - full)) <= 1e-6
+
+
+def test_ecc_match_f32_frames(stacker, small_stack):
+    # CV_32FC3 inputs (float TIFF/EXR): cvtColor gives 32FC1, which findTransformECC accepts;
+    # convert(CV_32F, 1/255) still scales by 1/255 (utils.rs:133)
+    frames, G = small_stack
+    f32 = [f.astype(np.float32) for f in frames[:3]]
+    out, stats = stacker.ecc_match(f32, PARAMS, return_stats=True)
+    ref, warps, iters = oracle.ecc_match(f32, max_count=5000, epsilon=1e-5, gauss_filt_size=5)
+    for i in (1, 2):
+        assert synth.corner_error(stats[i]["warp"], warps[i], 320, 240) <= 0.05
+        assert abs(stats[i]["iterations"] - int(iters[i])) <= 1
+    rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert np.percentile(rel[4:-4, 4:-4], 99.5) < 2e-3
+    # 16-bit frames: the reference's grey is 16UC1, which findTransformECC rejects -> OpenCvError
+    with pytest.raises(OpenCvError):
+        stacker.ecc_match([f.astype(np.uint16) for f in frames[:2]], PARAMS)
