@@ -49,6 +49,9 @@ def main() -> None:
     ap.add_argument("--cpu-sample-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = cores+1)")
     ap.add_argument("--ecc-slots", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine tuning knob name=value (stk_set_option)")
+    ap.add_argument("--no-reduce-overlap", action="store_true",
+                    help="N > 1: wait for the accumulator reduce before starting the next step (default: the reduce of step k "
+                         "runs under the alignment of step k+1, on a second accumulator)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the reduce goes through gloo/CPU "
                          "(checks the sharded code path, not a performance number)")
@@ -108,16 +111,44 @@ def main() -> None:
     st.set_option("profile_stride", max(1, args.profile_launches if args.profile_launches > 1 else 3))
     ecc_params = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
     kp_params = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
-    acc = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-    out = torch.empty_like(acc)
-    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    # two accumulators: while step k's sum is being reduced over xGMI, step k+1 aligns into the other one
+    accs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    cnts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(len(accs))]
+    out = torch.empty_like(accs[0])
+    overlap = world > 1 and not args.no_reduce_overlap
+    pending = None                                   # the previous step's reduce in flight: (works, acc, counts, staging)
+    step_no = 0
+    totals = [0, 0]                                  # frames folded / dropped in the last finished stack (rank 0)
 
     agg = {"ecc_iter_ms": 0.0, "ecc_iter_timed": 0, "ecc_iter_launches": 0, "ecc_slot_iterations": 0, "prep_ms": 0.0, "align_ms": 0.0,
            "warp_ms": 0.0, "warp_frames": 0, "warp_launches": 0}
     last_stats = None
 
+    def start_reduce(acc, counts):
+        """The path's one exchange: sum of the per-rank accumulators (+ two counters) to rank 0. RCCL over xGMI."""
+        if args.rehearse_on_one_gpu:                 # gloo on CPU copies: control-flow rehearsal only
+            stage = (acc.cpu(), counts.cpu())
+            works = [dist.reduce(stage[0], dst=0, op=dist.ReduceOp.SUM, async_op=True),
+                     dist.reduce(stage[1], dst=0, op=dist.ReduceOp.SUM, async_op=True)]
+            return (works, acc, counts, stage)
+        works = [dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM, async_op=True),
+                 dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM, async_op=True)]
+        return (works, acc, counts, None)
+
+    def finish_reduce(p):
+        works, acc, counts, stage = p
+        for w in works:
+            w.wait()                                 # RCCL: the current stream waits for the collective
+        if stage is not None:
+            acc.copy_(stage[0]); counts.copy_(stage[1])
+        if rank == 0:
+            totals[0], totals[1] = int(counts[0].item()), int(counts[1].item())
+            st.finalize_mean(acc, totals[0], out)
+
     def step(record: bool):
-        nonlocal last_stats
+        nonlocal last_stats, pending, step_no
+        acc, counts = accs[step_no % len(accs)], cnts[step_no % len(accs)]
+        step_no += 1
         if api == "ecc":
             added, stats = st.ecc_match_shard(frames, ecc_params, rank == 0, acc)
             dropped = 0
@@ -130,19 +161,28 @@ def main() -> None:
             last_stats = stats
         counts[0] = added
         counts[1] = dropped
-        if world > 1 and args.rehearse_on_one_gpu:
-            a_c, c_c = acc.cpu(), counts.cpu()
-            dist.reduce(a_c, dst=0, op=dist.ReduceOp.SUM)
-            dist.reduce(c_c, dst=0, op=dist.ReduceOp.SUM)
-            acc.copy_(a_c); counts.copy_(c_c)
-        elif world > 1:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)          # RCCL over xGMI: the path's one exchange
-            dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
-            torch.cuda.current_stream().synchronize()              # acc is rewritten by the next step
-        if rank == 0:
-            st.finalize_mean(acc, int(counts[0].item()), out)
+        if world == 1:
+            totals[0], totals[1] = added, dropped
+            st.finalize_mean(acc, added, out)
+            return
+        if pending is not None:                      # its reduce ran under the alignment that just finished
+            finish_reduce(pending)
+            pending = None
+        p = start_reduce(acc, counts)
+        if overlap:
+            pending = p
+        else:
+            finish_reduce(p)
+            torch.cuda.current_stream().synchronize()
+
+    def drain():
+        nonlocal pending
+        if pending is not None:
+            finish_reduce(pending)
+            pending = None
 
     def fence():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -176,7 +216,10 @@ def main() -> None:
                                    + ("ecc_match Homography max_count 5000 eps 1e-5 gauss 5" if api == "ecc"
                                       else "keypoint_match RANSAC thr 5.0 ratio 0.9 keep 0.80")
                                    + f", {fpg} frames/GPU resident in HBM, frame-sharded, one accumulator reduce",
-                       "frames_per_gpu": fpg, "width": W, "height": H, "parallelism": f"frame-shard x{world}"},
+                       "frames_per_gpu": fpg, "width": W, "height": H, "parallelism": f"frame-shard x{world}",
+                       "accumulator_reduce": ("none (1 GPU)" if world == 1 else
+                                              "RCCL reduce to rank 0, overlapped with the next step's alignment (double-buffered)"
+                                              if overlap else "RCCL reduce to rank 0, waited for before the next step")},
         }
         # ---- roofline of the dominant kernel --------------------------------------------------
         if api == "ecc" and agg["ecc_iter_timed"] > 0:
@@ -215,6 +258,7 @@ def main() -> None:
             "warp_accumulate_GBps_fused": round(warp_bytes / max(agg["warp_ms"], 1e-9) / 1e6, 1),
             "warp_accumulate_GBps_survey_bytes": round(agg["warp_frames"] * (src_b + 24 * px) / max(agg["warp_ms"], 1e-9) / 1e6, 1),
             "synthetic_generation_s": round(gen_s, 1),
+            "frames_folded_last_step": totals[0], "frames_dropped_last_step": totals[1],
         }
         # ---- CPU baseline: the oracle (a port of the reference's OpenCV/Rayon path) on host cores ----
         if not args.no_cpu_baseline and world == 1:
