@@ -130,3 +130,28 @@ def test_orb_bit_pattern_is_pinned():
     sk = "/opt/conda/lib/python3.9/site-packages/skimage/feature/orb_descriptor_positions.txt"
     if os.path.exists(sk):
         assert np.array_equal(np.loadtxt(sk).astype(np.int8).reshape(-1), table)
+
+
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """include/stacker.h must be consumable from C (the Rust shim's bindgen input): compile a C
+    translation unit against it, link it with the shared library and run the one call that needs no GPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "caller.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "stacker.h"\n'
+        "int main(void) {\n"
+        "    stk_keypoint_params kp; stk_ecc_params ep; stk_frames fr; stk_image_f32 im; stk_frame_stats fs; stk_timing tm;\n"
+        "    memset(&kp, 0, sizeof kp); memset(&ep, 0, sizeof ep); memset(&fr, 0, sizeof fr); memset(&im, 0, sizeof im);\n"
+        "    (void)fs; (void)tm; ep.motion_type = STK_MOTION_HOMOGRAPHY; kp.method = STK_METHOD_RANSAC;\n"
+        '    printf("%s %d %d\\n", stk_version(), (int)sizeof(stk_frame_stats), (int)STK_SHARPNESS_GLVN);\n'
+        "    return stk_ecc_match(NULL, &fr, &ep, 0.0f, &im, NULL) == STK_INVALID_PARAMS ? 0 : 1;\n"
+        "}\n")
+    exe = tmp_path / "caller"
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                         _ffi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(_ffi.LIB_PATH)], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    # torch's bundled HIP runtime is not on the loader path of a plain C program: point it at /opt/rocm like a Rust caller would
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.startswith("libstacker_rs_amd")
