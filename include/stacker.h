@@ -137,7 +137,7 @@ stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
  *                        at round-off level (within the stated ECC tolerance)
  *   "ecc_variant"        ECC pixel-pass kernel: 3 row-factorised (default), 0 direct, 1 LDS-tiled, 2 row-sharing
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
- *   "kp_workers"         host threads of the keypoint path (each with its own stream and ORB workspace)
+ *   "kp_workers"         host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
  *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table
  *                        (changes results: it selects the other OpenCV behaviour)
  *   "profile"            0 off, 1 per-stage events (stk_get_timing), 2 + event pairs around ECC launches

@@ -32,7 +32,7 @@ struct stk_ctx {
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
-    int opt_kp_workers = 8;       // host threads (each with its own stream and ORB workspace) of the keypoint path
+    int opt_kp_workers = 8;       // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 1152;    // total workgroups of one ECC iteration launch (all slots): more than the 768 the chip holds at
                                   // once, so the dispatcher balances the uneven rows-per-wave split (960 / 1344 measure worse)
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = row-factorised Hessian (homography, default), 0 = direct gathers,
@@ -45,10 +45,6 @@ struct stk_ctx {
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
     stk::KeypointWorkspace* kp = nullptr;
-    // keypoint path: moving frames are processed by `opt_kp_workers` host threads, each with its own workspace and
-    // stream (ORB is many small launches with host decisions in between: one frame cannot fill the GPU or hide the syncs)
-    std::vector<stk::KeypointWorkspace*> kp_workers;
-    std::vector<hipStream_t> kp_streams;
     std::mutex err_mutex;
 };
 

@@ -27,9 +27,10 @@ __device__ __forceinline__ void lin_coef(int d, int src, double scale, int& ofs,
 
 __global__ __launch_bounds__(256) void resize_exact_kernel(const uint8_t* __restrict__ src, int sw, int sh,
                                                            uint8_t* __restrict__ dst, int dw, int dh,
-                                                           double scale_x, double scale_y) {
+                                                           double scale_x, double scale_y, size_t frame_stride) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
+    src += blockIdx.z * frame_stride; dst += blockIdx.z * frame_stride;      // batched over frames
     int ox, cx0, cx1, oy, cy0, cy1;
     lin_coef(x, sw, scale_x, ox, cx0, cx1);
     lin_coef(y, sh, scale_y, oy, cy0, cy1);
@@ -42,10 +43,11 @@ __global__ __launch_bounds__(256) void resize_exact_kernel(const uint8_t* __rest
     dst[(size_t)y * dw + x] = (uint8_t)min((v + (1u << 15)) >> 16, 255u);
 }
 
-hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s) {
-    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s,
+                               int n_frames, size_t frame_stride) {
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_frames);
     const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
-    resize_exact_kernel<<<grid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, sx, sy);
+    resize_exact_kernel<<<grid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, sx, sy, frame_stride);
     return hipGetLastError();
 }
 
@@ -136,19 +138,25 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int 
     return best > thr ? best - 1 : 0;
 }
 
+// Batched over frames: blockIdx.z (or the named grid dimension) is the frame; per-frame arrays sit `*_stride`
+// elements apart (OrbBatch). n_frames = 1 and zero strides give the single-image form.
+struct OrbBatch { size_t pyr, states, cand, sel; };
+
 __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h, int thr,
-                                                         uint8_t* __restrict__ score) {
+                                                         uint8_t* __restrict__ score, OrbBatch bs) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    img += blockIdx.z * bs.pyr; score += blockIdx.z * bs.pyr;
     int s = 0;
     if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) s = fast_score_at(img + (size_t)y * w + x, w, thr);
     score[(size_t)y * w + x] = (uint8_t)s;
 }
 
 __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, int w, int h, int edge,
-                                                       OrbLevelState* st, OrbCandidate* cand, int cap) {
+                                                       OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63) + edge, y = blockIdx.y * 4 + (threadIdx.x >> 6) + edge;
     if (x >= w - edge || y >= h - edge) return;
+    score += blockIdx.z * bs.pyr; st += blockIdx.z * bs.states; cand += blockIdx.z * bs.cand;
     const uint8_t* c = score + (size_t)y * w + x;
     const int s = c[0];
     if (!s) return;
@@ -159,8 +167,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict
     }
 }
 
-__global__ void fast_threshold_kernel(OrbLevelState* st, int keep) {
+__global__ void fast_threshold_kernel(OrbLevelState* st, int keep, OrbBatch bs) {
     if (threadIdx.x != 0) return;
+    st += blockIdx.x * bs.states;
     int cum = 0, thr = 1;
     for (int s = 255; s >= 1; s--) {
         cum += st->hist[s];
@@ -173,7 +182,8 @@ __global__ void fast_threshold_kernel(OrbLevelState* st, int keep) {
 // Harris response (blockSize 7, Sobel-like 3x3 on the 8-bit level, integer sums) and the IC moments
 __global__ __launch_bounds__(64) void fast_select_kernel(const uint8_t* __restrict__ img, int w, int h,
                                                          OrbLevelState* st, const OrbCandidate* __restrict__ cand,
-                                                         int cap, OrbSelected* sel, int sel_cap, OrbUmax um) {
+                                                         int cap, OrbSelected* sel, int sel_cap, OrbUmax um, OrbBatch bs) {
+    img += blockIdx.y * bs.pyr; st += blockIdx.y * bs.states; cand += blockIdx.y * bs.cand; sel += blockIdx.y * bs.sel;
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int n = min(st->n_cand, cap);
     if (i >= n) return;
@@ -214,15 +224,17 @@ __global__ __launch_bounds__(64) void fast_select_kernel(const uint8_t* __restri
 
 hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
                              OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,
-                             const OrbUmax& um, hipStream_t s) {
-    dim3 grid((w + 63) / 64, (h + 3) / 4);
-    fast_score_kernel<<<grid, 256, 0, s>>>(img, w, h, thr, score);
+                             const OrbUmax& um, hipStream_t s, int n_frames, size_t pyr_stride, size_t states_stride,
+                             size_t cand_stride, size_t sel_stride) {
+    const OrbBatch bs{pyr_stride, states_stride, cand_stride, sel_stride};
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
+    fast_score_kernel<<<grid, 256, 0, s>>>(img, w, h, thr, score, bs);
     if (w > 2 * edge && h > 2 * edge) {
-        dim3 g2((w - 2 * edge + 63) / 64, (h - 2 * edge + 3) / 4);
-        fast_nms_kernel<<<g2, 256, 0, s>>>(score, w, h, edge, st, cand, cap);
+        dim3 g2((w - 2 * edge + 63) / 64, (h - 2 * edge + 3) / 4, n_frames);
+        fast_nms_kernel<<<g2, 256, 0, s>>>(score, w, h, edge, st, cand, cap, bs);
     }
-    fast_threshold_kernel<<<1, 64, 0, s>>>(st, keep);
-    fast_select_kernel<<<(cap + 63) / 64, 64, 0, s>>>(img, w, h, st, cand, cap, sel, sel_cap, um);
+    fast_threshold_kernel<<<n_frames, 64, 0, s>>>(st, keep, bs);
+    fast_select_kernel<<<dim3((cap + 63) / 64, n_frames), 64, 0, s>>>(img, w, h, st, cand, cap, sel, sel_cap, um, bs);
     return hipGetLastError();
 }
 
@@ -234,9 +246,10 @@ __device__ __forceinline__ int refl101(int p, int len) {
 }
 
 __global__ __launch_bounds__(256) void gauss7_rows_kernel(const uint8_t* __restrict__ src, int w, int h, Gauss7 k,
-                                                          float* __restrict__ tmp) {
+                                                          float* __restrict__ tmp, size_t pyr_stride, size_t tmp_stride) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    src += blockIdx.z * pyr_stride; tmp += blockIdx.z * tmp_stride;
     const uint8_t* s = src + (size_t)y * w;
     float acc = k.k[0] * (float)s[refl101(x - 3, w)];
 #pragma unroll
@@ -245,9 +258,10 @@ __global__ __launch_bounds__(256) void gauss7_rows_kernel(const uint8_t* __restr
 }
 
 __global__ __launch_bounds__(256) void gauss7_cols_kernel(const float* __restrict__ tmp, int w, int h, Gauss7 k,
-                                                          uint8_t* __restrict__ dst) {
+                                                          uint8_t* __restrict__ dst, size_t pyr_stride, size_t tmp_stride) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    tmp += blockIdx.z * tmp_stride; dst += blockIdx.z * pyr_stride;
     float acc = k.k[3] * tmp[(size_t)y * w + x];
 #pragma unroll
     for (int i = 1; i <= 3; i++)
@@ -256,10 +270,11 @@ __global__ __launch_bounds__(256) void gauss7_cols_kernel(const float* __restric
     dst[(size_t)y * w + x] = (uint8_t)min(max(r, 0), 255);
 }
 
-hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s) {
-    dim3 grid((w + 63) / 64, (h + 3) / 4);
-    gauss7_rows_kernel<<<grid, 256, 0, s>>>(src, w, h, k, tmp);
-    gauss7_cols_kernel<<<grid, 256, 0, s>>>(tmp, w, h, k, dst);
+hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s,
+                         int n_frames, size_t pyr_stride, size_t tmp_stride) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
+    gauss7_rows_kernel<<<grid, 256, 0, s>>>(src, w, h, k, tmp, pyr_stride, tmp_stride);
+    gauss7_cols_kernel<<<grid, 256, 0, s>>>(tmp, w, h, k, dst, pyr_stride, tmp_stride);
     return hipGetLastError();
 }
 
@@ -271,11 +286,11 @@ hipError_t upload_orb_pattern(const signed char* p) {
 }
 
 // one lane per descriptor byte: grid = n_keypoints blocks of 32 threads
-__global__ __launch_bounds__(32) void brief_kernel(const uint8_t* __restrict__ pyr_blur, OrbPyramid pyr,
+__global__ __launch_bounds__(32) void brief_kernel(const uint8_t* __restrict__ pyr_blur, OrbPyramid pyr, size_t pyr_stride,
                                                    const OrbFinalKeypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
     const OrbFinalKeypoint kp = kps[blockIdx.x];
     const int l = kp.level, w = pyr.w[l];
-    const uint8_t* center = pyr_blur + pyr.ofs[l] + (size_t)kp.cy * w + kp.cx;
+    const uint8_t* center = pyr_blur + kp.frame * pyr_stride + pyr.ofs[l] + (size_t)kp.cy * w + kp.cx;
     const float a = kp.cos_a, b = kp.sin_a;
     const int i = threadIdx.x;
     int val = 0;
@@ -289,21 +304,26 @@ __global__ __launch_bounds__(32) void brief_kernel(const uint8_t* __restrict__ p
         const int t1 = center[(int)__builtin_rintf(y1) * w + (int)__builtin_rintf(x1)];
         val |= (t0 < t1) << bit;
     }
-    desc[(size_t)blockIdx.x * 32 + i] = (uint8_t)val;
+    desc[(size_t)kp.row * 32 + i] = (uint8_t)val;
 }
 
 hipError_t launch_brief(const uint8_t* pyr_blur, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, uint8_t* desc,
-                        hipStream_t s) {
+                        hipStream_t s, size_t pyr_stride) {
     if (n <= 0) return hipSuccess;
-    brief_kernel<<<n, 32, 0, s>>>(pyr_blur, pyr, kps, desc);
+    brief_kernel<<<n, 32, 0, s>>>(pyr_blur, pyr, pyr_stride, kps, desc);
     return hipGetLastError();
 }
 
 // ---- brute-force Hamming 2-NN ---------------------------------------------------------------------------
+// blockIdx.y = train set (frame): its rows start `train_stride` rows after the previous set's, it has
+// train_counts[blockIdx.y] rows (nt when train_counts is null), and its result block is out + blockIdx.y * nq * 4.
 __global__ __launch_bounds__(64) void knn2_hamming_kernel(const uint8_t* __restrict__ query, int nq,
-                                                          const uint8_t* __restrict__ train, int nt, int* __restrict__ out) {
+                                                          const uint8_t* __restrict__ train, int nt, int* __restrict__ out,
+                                                          const int* __restrict__ train_counts, size_t train_stride) {
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= nq) return;
+    train += blockIdx.y * train_stride * 32; out += (size_t)blockIdx.y * nq * 4;
+    if (train_counts) nt = train_counts[blockIdx.y];
     const uint4* qa = reinterpret_cast<const uint4*>(query + (size_t)q * 32);
     const uint4 q0 = qa[0], q1 = qa[1];
     int i0 = -1, i1 = -1, d0 = 0x7fffffff, d1 = 0x7fffffff;
@@ -321,9 +341,10 @@ __global__ __launch_bounds__(64) void knn2_hamming_kernel(const uint8_t* __restr
     out[q * 4 + 2] = i1; out[q * 4 + 3] = i1 >= 0 ? d1 : -1;
 }
 
-hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s) {
-    if (nq <= 0) return hipSuccess;
-    knn2_hamming_kernel<<<(nq + 63) / 64, 64, 0, s>>>(query, nq, train, nt, out);
+hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s,
+                               int n_sets, const int* train_counts, size_t train_stride) {
+    if (nq <= 0 || n_sets <= 0) return hipSuccess;
+    knn2_hamming_kernel<<<dim3((nq + 63) / 64, n_sets), 64, 0, s>>>(query, nq, train, nt, out, train_counts, train_stride);
     return hipGetLastError();
 }
 

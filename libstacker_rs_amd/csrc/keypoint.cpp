@@ -24,18 +24,18 @@ using namespace stk;
 namespace stk {
 
 struct KeypointWorkspace {
-    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn, gfull;
+    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn, gfull, counts;
     bool pattern_uploaded = false;
-    OrbSelected* host_sel = nullptr;        // pinned
-    OrbLevelState* host_states = nullptr;   // pinned
+    OrbSelected* host_sel = nullptr;        // pinned: [frames][ORB_LEVELS][ORB_PACK] head of every short list
+    OrbLevelState* host_states = nullptr;   // pinned: [frames][ORB_LEVELS]
     int* host_knn = nullptr;                // pinned
-    size_t host_knn_cap = 0;
+    size_t host_knn_cap = 0, host_frames_cap = 0;
 };
 
 KeypointWorkspace* keypoint_workspace_create() { return new KeypointWorkspace(); }
 void keypoint_workspace_destroy(KeypointWorkspace* k) {
     if (!k) return;
-    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn, &k->gfull})
+    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn, &k->gfull, &k->counts})
         b->release();
     if (k->host_sel) (void)hipHostFree(k->host_sel);
     if (k->host_states) (void)hipHostFree(k->host_states);
@@ -121,97 +121,145 @@ void retain_best(std::vector<T>& v, int n, F resp) {
     v.swap(o);
 }
 
-// ORB on an 8-bit grey image that already sits in level 0 of the workspace pyramid.
-// Descriptors are left on the device in `desc_dev` (n x 32 bytes).
-stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const OrbGeometry& g, uint8_t* desc_dev,
-                   size_t desc_cap_rows, std::vector<HostKeypoint>& out) {
+constexpr size_t MAX_KP = 4096;   // descriptor rows per frame (500 + ties)
+constexpr int ORB_PACK = 512;     // short-list entries per level fetched in the one strided copy (2 n_l + ties fit; else a 2nd copy)
+
+// run `fn(i)` for i in [0, n) on up to `threads` host threads (pure host work: no HIP calls inside)
+template <typename F>
+void parallel_for(int n, int threads, F fn) {
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i); } });
+    for (auto& t : pool) t.join();
+}
+
+// ORB on `n_frames` 8-bit grey images that already sit in level 0 of the workspace pyramids (frame f at
+// pyr + f * g.pyr.total). Every device stage is ONE launch per level for all frames; the host steps in between
+// (Harris cull, ordering, angles) run on `threads` host threads. Descriptors are left on the device in `desc_dev`,
+// frame f in rows [f * MAX_KP, f * MAX_KP + out[f].size()).
+stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const OrbGeometry& g, int n_frames, int threads,
+                   uint8_t* desc_dev, std::vector<std::vector<HostKeypoint>>& out) {
     uint8_t* pyr = ws->pyr.as<uint8_t>();
     uint8_t* score = ws->score.as<uint8_t>();
     OrbLevelState* st = ws->states.as<OrbLevelState>();
-    HIP_TRY(hipMemsetAsync(st, 0, sizeof(OrbLevelState) * ORB_LEVELS, s));
+    const size_t PT = g.pyr.total, SELF = (size_t)ORB_SEL_CAP * ORB_LEVELS;
+    const size_t tmp_stride = (size_t)g.pyr.w[0] * g.pyr.h[0];
+    HIP_TRY(hipMemsetAsync(st, 0, sizeof(OrbLevelState) * ORB_LEVELS * n_frames, s));
     for (int l = 1; l < ORB_LEVELS; l++)
-        HIP_TRY(launch_resize_exact(pyr + g.pyr.ofs[l - 1], g.pyr.w[l - 1], g.pyr.h[l - 1], pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], s));
+        HIP_TRY(launch_resize_exact(pyr + g.pyr.ofs[l - 1], g.pyr.w[l - 1], g.pyr.h[l - 1], pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], s,
+                                    n_frames, PT));
     for (int l = 0; l < ORB_LEVELS; l++) {
         const int lw = g.pyr.w[l], lh = g.pyr.h[l];
         if (lw <= 6 || lh <= 6) continue;
         HIP_TRY(launch_fast_level(pyr + g.pyr.ofs[l], lw, lh, ORB_FAST_THRESHOLD, ORB_EDGE, 2 * g.nfeatures[l], score + g.pyr.ofs[l],
                                   st + l, ws->cand.as<OrbCandidate>() + g.cand_ofs[l], (int)g.cand_cap[l],
-                                  ws->sel.as<OrbSelected>() + (size_t)l * ORB_SEL_CAP, ORB_SEL_CAP, g.umax, s));
+                                  ws->sel.as<OrbSelected>() + (size_t)l * ORB_SEL_CAP, ORB_SEL_CAP, g.umax, s,
+                                  n_frames, PT, ORB_LEVELS, g.cand_total, SELF));
     }
-    HIP_TRY(hipMemcpyAsync(ws->host_states, st, sizeof(OrbLevelState) * ORB_LEVELS, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ws->host_states, st, sizeof(OrbLevelState) * ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, s));
+    // the head of every short list in one strided copy (rows = (frame, level), ORB_PACK of ORB_SEL_CAP entries each)
+    HIP_TRY(hipMemcpy2DAsync(ws->host_sel, sizeof(OrbSelected) * ORB_PACK, ws->sel.p, sizeof(OrbSelected) * ORB_SEL_CAP,
+                             sizeof(OrbSelected) * ORB_PACK, (size_t)ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    for (int l = 0; l < ORB_LEVELS; l++) {
-        const int n = std::min(ws->host_states[l].n_sel, ORB_SEL_CAP);
-        if (ws->host_states[l].n_sel > ORB_SEL_CAP)
-            return fail(ctx, STK_PROCESSING_ERROR, "ORB: more tied FAST corners than the short list holds");
-        if (n > 0)
-            HIP_TRY(hipMemcpyAsync(ws->host_sel + (size_t)l * ORB_SEL_CAP, ws->sel.as<OrbSelected>() + (size_t)l * ORB_SEL_CAP,
-                                   sizeof(OrbSelected) * n, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
-
-    out.clear();
-    std::vector<OrbFinalKeypoint> fin;
-    for (int l = 0; l < ORB_LEVELS; l++) {
-        const int n = std::min(ws->host_states[l].n_sel, ORB_SEL_CAP);
-        std::vector<OrbSelected> v(ws->host_sel + (size_t)l * ORB_SEL_CAP, ws->host_sel + (size_t)l * ORB_SEL_CAP + n);
-        // cull to n_l by the Harris response (ties kept), then a deterministic order
-        retain_best(v, g.nfeatures[l], [](const OrbSelected& k) { return k.harris; });
-        std::sort(v.begin(), v.end(), [](const OrbSelected& p, const OrbSelected& q) {
-            if (p.harris != q.harris) return p.harris > q.harris;
-            const int py = p.xy >> 16, qy = q.xy >> 16;
-            if (py != qy) return py < qy;
-            return (p.xy & 0xffff) < (q.xy & 0xffff);
-        });
-        for (const OrbSelected& k : v) {
-            HostKeypoint hk;
-            hk.lx = k.xy & 0xffff; hk.ly = k.xy >> 16; hk.octave = l;
-            hk.response = k.harris;
-            hk.angle = fast_atan2((float)k.m01, (float)k.m10);
-            hk.size = 31 * g.scale[l];
-            hk.x = (float)hk.lx * g.scale[l]; hk.y = (float)hk.ly * g.scale[l];
-            out.push_back(hk);
-            // computeOrbDescriptors: centre = cvRound(pt * (1/scale)), a = cos(angle deg->rad), b = sin
-            const float inv = 1.f / g.scale[l];
-            float ang = hk.angle;
-            ang *= (float)(3.14159265358979323846 / 180.f);
-            OrbFinalKeypoint f;
-            f.level = l; f.cx = cv_round_f(hk.x * inv); f.cy = cv_round_f(hk.y * inv);
-            f.cos_a = (float)std::cos(ang); f.sin_a = (float)std::sin(ang);
-            fin.push_back(f);
+    // rare: a level with more short-listed corners than ORB_PACK (many tied FAST scores) is fetched whole
+    std::vector<std::vector<OrbSelected>> big((size_t)n_frames * ORB_LEVELS);
+    for (int f = 0; f < n_frames; f++)
+        for (int l = 0; l < ORB_LEVELS; l++) {
+            const int n = ws->host_states[f * ORB_LEVELS + l].n_sel;
+            if (n > ORB_SEL_CAP) return fail(ctx, STK_PROCESSING_ERROR, "ORB: more tied FAST corners than the short list holds");
+            if (n > ORB_PACK) {
+                auto& v = big[(size_t)f * ORB_LEVELS + l];
+                v.resize(n);
+                HIP_TRY(hipMemcpy(v.data(), ws->sel.as<OrbSelected>() + (size_t)f * SELF + (size_t)l * ORB_SEL_CAP,
+                                  sizeof(OrbSelected) * n, hipMemcpyDeviceToHost));
+            }
         }
-    }
-    if (out.size() > desc_cap_rows) { out.resize(desc_cap_rows); fin.resize(desc_cap_rows); }
-    if (fin.empty()) return STK_OK;
-    HIP_TRY(ws->final_kps.reserve(sizeof(OrbFinalKeypoint) * fin.size()));
-    HIP_TRY(hipMemcpyAsync(ws->final_kps.p, fin.data(), sizeof(OrbFinalKeypoint) * fin.size(), hipMemcpyHostToDevice, s));
-    bool have[ORB_LEVELS] = {false};
-    for (const auto& f : fin) have[f.level] = true;
+
+    out.assign(n_frames, {});
+    std::vector<std::vector<OrbFinalKeypoint>> fins(n_frames);
+    parallel_for(n_frames, threads, [&](int f) {
+        std::vector<HostKeypoint>& o = out[f];
+        std::vector<OrbFinalKeypoint>& fin = fins[f];
+        for (int l = 0; l < ORB_LEVELS; l++) {
+            const int n = ws->host_states[f * ORB_LEVELS + l].n_sel;
+            const auto& bv = big[(size_t)f * ORB_LEVELS + l];
+            const OrbSelected* src = n > ORB_PACK ? bv.data() : ws->host_sel + ((size_t)f * ORB_LEVELS + l) * ORB_PACK;
+            std::vector<OrbSelected> v(src, src + n);
+            // cull to n_l by the Harris response (ties kept), then a deterministic order
+            retain_best(v, g.nfeatures[l], [](const OrbSelected& k) { return k.harris; });
+            std::sort(v.begin(), v.end(), [](const OrbSelected& p, const OrbSelected& q) {
+                if (p.harris != q.harris) return p.harris > q.harris;
+                const int py = p.xy >> 16, qy = q.xy >> 16;
+                if (py != qy) return py < qy;
+                return (p.xy & 0xffff) < (q.xy & 0xffff);
+            });
+            for (const OrbSelected& k : v) {
+                HostKeypoint hk;
+                hk.lx = k.xy & 0xffff; hk.ly = k.xy >> 16; hk.octave = l;
+                hk.response = k.harris;
+                hk.angle = fast_atan2((float)k.m01, (float)k.m10);
+                hk.size = 31 * g.scale[l];
+                hk.x = (float)hk.lx * g.scale[l]; hk.y = (float)hk.ly * g.scale[l];
+                o.push_back(hk);
+                // computeOrbDescriptors: centre = cvRound(pt * (1/scale)), a = cos(angle deg->rad), b = sin
+                const float inv = 1.f / g.scale[l];
+                float ang = hk.angle;
+                ang *= (float)(3.14159265358979323846 / 180.f);
+                OrbFinalKeypoint fk;
+                fk.level = l; fk.cx = cv_round_f(hk.x * inv); fk.cy = cv_round_f(hk.y * inv);
+                fk.cos_a = (float)std::cos(ang); fk.sin_a = (float)std::sin(ang);
+                fk.frame = f; fk.row = 0;
+                fin.push_back(fk);
+            }
+        }
+        if (o.size() > MAX_KP) { o.resize(MAX_KP); fin.resize(MAX_KP); }
+        for (size_t k = 0; k < fin.size(); k++) fin[k].row = (int)((size_t)f * MAX_KP + k);
+    });
+    std::vector<OrbFinalKeypoint> all;
+    for (auto& fin : fins) all.insert(all.end(), fin.begin(), fin.end());
+    if (all.empty()) return STK_OK;
+    HIP_TRY(ws->final_kps.reserve(sizeof(OrbFinalKeypoint) * all.size()));
+    HIP_TRY(hipMemcpyAsync(ws->final_kps.p, all.data(), sizeof(OrbFinalKeypoint) * all.size(), hipMemcpyHostToDevice, s));
     for (int l = 0; l < ORB_LEVELS; l++)
-        if (have[l])
-            HIP_TRY(launch_gauss7(pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], g.g7, ws->tmpf.as<float>(), ws->blur.as<uint8_t>() + g.pyr.ofs[l], s));
-    HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)fin.size(), desc_dev, s));
-    HIP_TRY(hipStreamSynchronize(s));     // `fin` is read by the async copy above
+        HIP_TRY(launch_gauss7(pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], g.g7, ws->tmpf.as<float>(), ws->blur.as<uint8_t>() + g.pyr.ofs[l], s,
+                              n_frames, PT, tmp_stride));
+    HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)all.size(), desc_dev, s, PT));
+    HIP_TRY(hipStreamSynchronize(s));     // `all` is read by the async copy above
     return STK_OK;
 }
 
-stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeometry& g) {
+stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeometry& g, int n_frames = 1) {
     orb_geometry(w, h, g);
-    HIP_TRY(ws->pyr.reserve(g.pyr.total));
-    HIP_TRY(ws->score.reserve(g.pyr.total));
-    HIP_TRY(ws->blur.reserve(g.pyr.total));
-    HIP_TRY(ws->tmpf.reserve((size_t)w * h * sizeof(float)));
-    HIP_TRY(ws->cand.reserve(g.cand_total * sizeof(OrbCandidate)));
-    HIP_TRY(ws->sel.reserve(sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS));
-    HIP_TRY(ws->states.reserve(sizeof(OrbLevelState) * ORB_LEVELS));
-    if (!ws->host_sel) HIP_TRY(hipHostMalloc((void**)&ws->host_sel, sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS, hipHostMallocDefault));
-    if (!ws->host_states) HIP_TRY(hipHostMalloc((void**)&ws->host_states, sizeof(OrbLevelState) * ORB_LEVELS, hipHostMallocDefault));
-    // the BRIEF pattern lives in __constant__ memory of the module: uploaded once, by the main workspace
-    if (ws == ctx->kp && !ws->pattern_uploaded) { HIP_TRY(upload_orb_pattern(ORB_BIT_PATTERN_31)); ws->pattern_uploaded = true; }
+    const size_t F = (size_t)std::max(n_frames, 1);
+    HIP_TRY(ws->pyr.reserve(g.pyr.total * F));
+    HIP_TRY(ws->score.reserve(g.pyr.total * F));
+    HIP_TRY(ws->blur.reserve(g.pyr.total * F));
+    HIP_TRY(ws->tmpf.reserve((size_t)w * h * sizeof(float) * F));
+    HIP_TRY(ws->cand.reserve(g.cand_total * sizeof(OrbCandidate) * F));
+    HIP_TRY(ws->sel.reserve(sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS * F));
+    HIP_TRY(ws->states.reserve(sizeof(OrbLevelState) * ORB_LEVELS * F));
+    if (ws->host_frames_cap < F) {
+        if (ws->host_sel) (void)hipHostFree(ws->host_sel);
+        if (ws->host_states) (void)hipHostFree(ws->host_states);
+        ws->host_sel = nullptr; ws->host_states = nullptr; ws->host_frames_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&ws->host_sel, sizeof(OrbSelected) * ORB_PACK * ORB_LEVELS * F, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&ws->host_states, sizeof(OrbLevelState) * ORB_LEVELS * F, hipHostMallocDefault));
+        ws->host_frames_cap = F;
+    }
+    // the BRIEF pattern lives in __constant__ memory of the module: uploaded once
+    if (!ws->pattern_uploaded) { HIP_TRY(upload_orb_pattern(ORB_BIT_PATTERN_31)); ws->pattern_uploaded = true; }
     return STK_OK;
 }
 
-constexpr size_t MAX_KP = 4096;   // descriptor rows per frame (500 + ties)
+// device bytes one frame needs in the batched ORB workspace (pyramid x3, f32 scratch, candidates, short lists, descriptors)
+size_t orb_bytes_per_frame(const OrbGeometry& g) {
+    return g.pyr.total * 3 + (size_t)g.pyr.w[0] * g.pyr.h[0] * sizeof(float) + g.cand_total * sizeof(OrbCandidate) +
+           sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS + MAX_KP * 32;
+}
+
 
 struct Match { int q, t; float d; };
 
@@ -233,8 +281,9 @@ stk_status stk_orb_detect_and_compute(stk_ctx* ctx, const uint8_t* grey, int32_t
     HIP_TRY(ws->desc.reserve(MAX_KP * 32));
     HIP_TRY(hipMemcpyAsync(ws->pyr.p, grey, (size_t)width * height,
                            location == STK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
-    std::vector<HostKeypoint> kps;
-    if ((st = orb_run(ctx, ws, ctx->stream, g, ws->desc.as<uint8_t>(), MAX_KP, kps))) return st;
+    std::vector<std::vector<HostKeypoint>> kpsv;
+    if ((st = orb_run(ctx, ws, ctx->stream, g, 1, 1, ws->desc.as<uint8_t>(), kpsv))) return st;
+    const std::vector<HostKeypoint>& kps = kpsv[0];
     const int n = (int)std::min<size_t>(kps.size(), (size_t)max_keypoints);
     for (int i = 0; i < n; i++) {
         float* o = keypoints + (size_t)i * 7;
@@ -335,133 +384,113 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     if ((st = resolve_frames(ctx, frames, dev))) return st;
     const size_t rb = frame_row_bytes(frames);
     OrbGeometry g;
-    if ((st = orb_prepare(ctx, ctx->kp, ew, eh, g))) return st;
-    KeypointWorkspace* ws0 = ctx->kp;
-    // per-workspace buffers beyond ORB's own: descriptors, 2-NN result, the full-size grey when scaling
-    auto prepare_match_buffers = [&](KeypointWorkspace* ws) -> stk_status {
-        if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
-        HIP_TRY(ws->desc.reserve(MAX_KP * 32));
-        HIP_TRY(ws->knn.reserve(MAX_KP * 16));
-        if (ws->host_knn_cap < MAX_KP * 4) {
-            if (ws->host_knn) (void)hipHostFree(ws->host_knn);
-            HIP_TRY(hipHostMalloc((void**)&ws->host_knn, MAX_KP * 16, hipHostMallocDefault));
-            ws->host_knn_cap = MAX_KP * 4;
-        }
-        return STK_OK;
-    };
-    // grey of a frame into level 0 of the ORB pyramid, through scale_image when scaling (utils.rs:186-214)
-    auto grey_level0 = [&](const void* frame, KeypointWorkspace* ws, hipStream_t s) -> stk_status {
-        if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->pyr.p, s)); return STK_OK; }
+    orb_geometry(ew, eh, g);
+    // frames per ORB batch: the whole shard when it fits a 32 GiB workspace (it does for every BASELINE config), else chunks
+    const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)32 << 30) / orb_bytes_per_frame(g)));
+    if ((st = orb_prepare(ctx, ctx->kp, ew, eh, g, batch))) return st;
+    KeypointWorkspace* ws = ctx->kp;
+    hipStream_t s = ctx->stream;
+    const int threads = ctx->opt_kp_workers;
+    if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
+    HIP_TRY(ws->desc0.reserve(MAX_KP * 32));
+    HIP_TRY(ws->desc.reserve(MAX_KP * 32 * (size_t)batch));
+    HIP_TRY(ws->knn.reserve(MAX_KP * 16 * (size_t)batch));
+    HIP_TRY(ws->counts.reserve(sizeof(int) * (size_t)batch));
+    if (ws->host_knn_cap < MAX_KP * 4 * (size_t)batch) {
+        if (ws->host_knn) (void)hipHostFree(ws->host_knn);
+        ws->host_knn = nullptr; ws->host_knn_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&ws->host_knn, MAX_KP * 16 * (size_t)batch, hipHostMallocDefault));
+        ws->host_knn_cap = MAX_KP * 4 * (size_t)batch;
+    }
+    // grey of a frame into level 0 of pyramid `slot`, through scale_image when scaling (utils.rs:186-214)
+    auto grey_level0 = [&](const void* frame, int slot) -> stk_status {
+        uint8_t* l0 = ws->pyr.as<uint8_t>() + (size_t)slot * g.pyr.total;
+        if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, l0, s)); return STK_OK; }
         HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->gfull.p, s));
-        HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, ws->pyr.as<uint8_t>(), ew, eh, s));
+        HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, l0, ew, eh, s));
         return STK_OK;
     };
     const double fix_sx = (double)w / (double)ew, fix_sy = (double)h / (double)eh;   // adjust_homography_for_scale_f64
-    HIP_TRY(ws0->desc0.reserve(MAX_KP * 32));
-    if ((st = prepare_match_buffers(ws0))) return st;
     if (stats) std::memset(stats, 0, sizeof(stk_frame_stats) * n);
 
-    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    // reference frame: grey -> ORB, descriptors stay in desc0 (lib.rs:161-175)
-    if ((st = grey_level0(dev[0], ws0, ctx->stream))) return st;
-    std::vector<HostKeypoint> kp0;
-    if ((st = orb_run(ctx, ws0, ctx->stream, g, ws0->desc0.as<uint8_t>(), MAX_KP, kp0))) return st;   // ends synchronised
-    const int n0 = (int)kp0.size();
-    if (stats) { stats[0].n_keypoints = n0; stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1; }
-    const uint8_t* desc0 = ws0->desc0.as<uint8_t>();
-
-    // one moving frame: ORB -> 2-NN against frame 0 -> ratio / sort / truncate -> homography. Independent of every
-    // other moving frame (lib.rs:185-290 is the body of a Rayon map), so frames are dealt to worker threads.
+    HIP_TRY(hipEventRecord(ctx->ev[0], s));
     struct FrameResult { bool ok = false; double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; int nk = 0, n_matches = 0, n_inl = 0; };
     std::vector<FrameResult> results(n);
-    auto process_frame = [&](int i, KeypointWorkspace* ws, hipStream_t s, std::vector<HostKeypoint>& kp, std::vector<Match>& ms) -> stk_status {
-        stk_status fs;
-        if ((fs = grey_level0(dev[i], ws, s))) return fs;
-        if ((fs = orb_run(ctx, ws, s, g, ws->desc.as<uint8_t>(), MAX_KP, kp))) return fs;
-        FrameResult& R = results[i];
-        const int nk = (int)kp.size();
-        R.nk = nk;
-        bool ok = true;
-        double* H = R.H;
-        ms.clear();
+    std::vector<HostKeypoint> kp0;
+    int n0 = 0;
+    // Batches of frames go through ORB together (one launch per stage and level for the whole batch); the first batch
+    // starts with the reference frame, whose descriptors are kept in desc0 (lib.rs:161-175). Every moving frame is
+    // independent of the others (lib.rs:185-290 is the body of a Rayon map).
+    for (int b0 = 0; b0 < n; b0 += batch) {
+        const int nb = std::min(batch, n - b0);
+        for (int k = 0; k < nb; k++)
+            if ((st = grey_level0(dev[b0 + k], k))) return st;
+        std::vector<std::vector<HostKeypoint>> kps;
+        if ((st = orb_run(ctx, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps))) return st;   // ends synchronised
+        int first = 0;                                         // first moving frame of this batch
+        if (b0 == 0) {
+            kp0 = kps[0];
+            n0 = (int)kp0.size();
+            if (n0 > 0) HIP_TRY(hipMemcpyAsync(ws->desc0.p, ws->desc.p, (size_t)n0 * 32, hipMemcpyDeviceToDevice, s));
+            if (stats) { stats[0].n_keypoints = n0; stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1; }
+            first = 1;
+        }
+        const int n_mov = nb - first;
+        if (n_mov <= 0) continue;
+        const int* knn_host = ws->host_knn;
         if (n0 > 0) {
-            // knn_match(query = frame-0 descriptors, train = frame-i descriptors, k = 2)  lib.rs:208-219
-            HIP_TRY(launch_knn2_hamming(desc0, n0, ws->desc.as<uint8_t>(), nk, ws->knn.as<int>(), s));
-            HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n0 * 16, hipMemcpyDeviceToHost, s));
+            // knn_match(query = frame-0 descriptors, train = frame-i descriptors, k = 2) for the whole batch  lib.rs:208-219
+            std::vector<int> cnt(nb);
+            for (int k = 0; k < nb; k++) cnt[k] = (int)kps[k].size();
+            HIP_TRY(hipMemcpyAsync(ws->counts.p, cnt.data(), sizeof(int) * nb, hipMemcpyHostToDevice, s));
+            HIP_TRY(launch_knn2_hamming(ws->desc0.as<uint8_t>(), n0, ws->desc.as<uint8_t>() + (size_t)first * MAX_KP * 32, 0,
+                                        ws->knn.as<int>(), s, n_mov, ws->counts.as<int>() + first, MAX_KP));
+            HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            const int* knn = ws->host_knn;
-            for (int q = 0; q < n0; q++) {
-                if (knn[q * 4] < 0 || knn[q * 4 + 2] < 0) continue;                 // m.len() == 2
-                const float d0 = (float)knn[q * 4 + 1], d1 = (float)knn[q * 4 + 3];
-                if (d0 < params->match_ratio * d1) ms.push_back({q, knn[q * 4], d0});   // Lowe ratio lib.rs:224
-            }
-            std::stable_sort(ms.begin(), ms.end(), [](const Match& a, const Match& b) { return a.d < b.d; });   // lib.rs:233
-            const size_t keep = (size_t)std::round((float)ms.size() * params->match_keep_ratio);              // lib.rs:235
-            if (keep < ms.size()) ms.resize(keep);
         }
-        if (ms.size() < 5) ok = false;                                               // lib.rs:240
-        else {
-            std::vector<float> sp(ms.size() * 2), dp(ms.size() * 2);
-            std::vector<uint8_t> mask(ms.size());
-            for (size_t k = 0; k < ms.size(); k++) {
-                sp[2 * k] = kp0[ms[k].q].x; sp[2 * k + 1] = kp0[ms[k].q].y;          // src_pts: frame 0  lib.rs:245-253
-                dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;            // dst_pts: frame i  lib.rs:256-264
-            }
-            int found = 0;
-            const int rc = geom::find_homography(dp.data(), sp.data(), (int)ms.size(), params->method,
-                                                 params->ransac_reproj_threshold, H, mask.data(), &found);   // lib.rs:267
-            if (rc != 0 || !found) ok = false;                                       // Err(_) | empty -> skip  lib.rs:275-282
-            else {
-                const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
-                if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284 / 521 (on the small-image H)
-                else if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
-                for (uint8_t m : mask) R.n_inl += m;
-            }
-        }
-        R.ok = ok; R.n_matches = (int)ms.size();
-        return STK_OK;
-    };
-
-    const int n_moving = n - 1;
-    const int n_workers = std::max(1, std::min(ctx->opt_kp_workers, n_moving));
-    if (n_moving > 0 && n_workers == 1) {
-        std::vector<HostKeypoint> kp;
-        std::vector<Match> ms;
-        for (int i = 1; i < n; i++)
-            if ((st = process_frame(i, ws0, ctx->stream, kp, ms))) return st;
-    } else if (n_moving > 0) {
-        while ((int)ctx->kp_workers.size() < n_workers) {
-            hipStream_t ns = nullptr;
-            HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
-            ctx->kp_streams.push_back(ns);
-            ctx->kp_workers.push_back(keypoint_workspace_create());
-        }
-        for (int k = 0; k < n_workers; k++) {                 // all allocation happens here, on the calling thread
-            OrbGeometry gk;
-            if ((st = orb_prepare(ctx, ctx->kp_workers[k], ew, eh, gk))) return st;
-            if ((st = prepare_match_buffers(ctx->kp_workers[k]))) return st;
-        }
-        HIP_TRY(hipDeviceSynchronize());                       // allocations / pattern upload visible to every stream
-        std::atomic<int> next{1};
-        std::vector<stk_status> wst(n_workers, STK_OK);
-        std::vector<std::thread> pool;
-        for (int k = 0; k < n_workers; k++)
-            pool.emplace_back([&, k]() {
-                (void)hipSetDevice(ctx->device);
-                std::vector<HostKeypoint> kp;
-                std::vector<Match> ms;
-                for (;;) {
-                    const int i = next.fetch_add(1);
-                    if (i >= n) break;
-                    const stk_status fs = process_frame(i, ctx->kp_workers[k], ctx->kp_streams[k], kp, ms);
-                    if (fs) { wst[k] = fs; next.store(n); break; }
+        parallel_for(n_mov, threads, [&](int m) {
+            const int i = b0 + first + m;
+            const std::vector<HostKeypoint>& kp = kps[first + m];
+            FrameResult& R = results[i];
+            R.nk = (int)kp.size();
+            bool ok = true;
+            double* H = R.H;
+            std::vector<Match> ms;
+            if (n0 > 0) {
+                const int* knn = knn_host + (size_t)m * n0 * 4;
+                for (int q = 0; q < n0; q++) {
+                    if (knn[q * 4] < 0 || knn[q * 4 + 2] < 0) continue;                 // m.len() == 2
+                    const float d0 = (float)knn[q * 4 + 1], d1 = (float)knn[q * 4 + 3];
+                    if (d0 < params->match_ratio * d1) ms.push_back({q, knn[q * 4], d0});   // Lowe ratio lib.rs:224
                 }
-            });
-        for (auto& t : pool) t.join();
-        for (stk_status fs : wst) if (fs) return fs;           // the message of the (last) failing worker is in ctx->err
+                std::stable_sort(ms.begin(), ms.end(), [](const Match& a, const Match& b) { return a.d < b.d; });   // lib.rs:233
+                const size_t keep = (size_t)std::round((float)ms.size() * params->match_keep_ratio);              // lib.rs:235
+                if (keep < ms.size()) ms.resize(keep);
+            }
+            if (ms.size() < 5) ok = false;                                               // lib.rs:240
+            else {
+                std::vector<float> sp(ms.size() * 2), dp(ms.size() * 2);
+                std::vector<uint8_t> mask(ms.size());
+                for (size_t k = 0; k < ms.size(); k++) {
+                    sp[2 * k] = kp0[ms[k].q].x; sp[2 * k + 1] = kp0[ms[k].q].y;          // src_pts: frame 0  lib.rs:245-253
+                    dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;            // dst_pts: frame i  lib.rs:256-264
+                }
+                int found = 0;
+                const int rc = geom::find_homography(dp.data(), sp.data(), (int)ms.size(), params->method,
+                                                     params->ransac_reproj_threshold, H, mask.data(), &found);   // lib.rs:267
+                if (rc != 0 || !found) ok = false;                                       // Err(_) | empty -> skip  lib.rs:275-282
+                else {
+                    const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
+                    if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284 / 521 (on the small-image H)
+                    else if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
+                    for (uint8_t mk : mask) R.n_inl += mk;
+                }
+            }
+            R.ok = ok; R.n_matches = (int)ms.size();
+        });
     }
 
-    // fold order = frame order, whatever the workers' completion order was: the f32 sum is reproducible
+    // fold order = frame order: the f32 sum is reproducible
     std::vector<WarpFrame> wf;
     wf.reserve(n);
     const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

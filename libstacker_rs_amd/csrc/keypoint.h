@@ -16,13 +16,15 @@ struct OrbLevelState { int hist[256]; int n_cand; int threshold; int n_sel; int 
 struct OrbUmax { int u[16]; };
 struct Gauss7 { float k[7]; };
 struct OrbPyramid { int w[ORB_LEVELS], h[ORB_LEVELS]; size_t ofs[ORB_LEVELS]; size_t total; };
-struct OrbFinalKeypoint { int level, cx, cy; float cos_a, sin_a; };
+struct OrbFinalKeypoint { int level, cx, cy; float cos_a, sin_a; int frame, row; };   // row: descriptor row to write
 
 struct KeypointWorkspace;
 KeypointWorkspace* keypoint_workspace_create();
 void keypoint_workspace_destroy(KeypointWorkspace*);
 
-hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s);
+// The ORB launchers are batched over frames: n_frames images whose per-frame arrays sit `*_stride` elements apart.
+hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s,
+                               int n_frames = 1, size_t frame_stride = 0);
 hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s);
 // scale_image's target size (utils.rs:186-214): the SMALLER dimension becomes scale_down, `as i32` truncation
 inline bool scaled_size(int w, int h, float scale_down, int& nw, int& nh) {
@@ -32,11 +34,15 @@ inline bool scaled_size(int w, int h, float scale_down, int& nw, int& nh) {
 }
 hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
                              OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,
-                             const OrbUmax& um, hipStream_t s);
-hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s);
+                             const OrbUmax& um, hipStream_t s, int n_frames = 1, size_t pyr_stride = 0,
+                             size_t states_stride = 0, size_t cand_stride = 0, size_t sel_stride = 0);
+hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s,
+                         int n_frames = 1, size_t pyr_stride = 0, size_t tmp_stride = 0);
 hipError_t upload_orb_pattern(const signed char* p);
 hipError_t launch_brief(const uint8_t* pyr_blur, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, uint8_t* desc,
-                        hipStream_t s);
-hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s);
+                        hipStream_t s, size_t pyr_stride = 0);
+// n_sets train sets against one query set; set k = rows [k * train_stride, k * train_stride + train_counts[k])
+hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s,
+                               int n_sets = 1, const int* train_counts = nullptr, size_t train_stride = 0);
 
 }  // namespace stk

@@ -94,8 +94,6 @@ void stk_destroy(stk_ctx* ctx) {
                       &ctx->partials, &ctx->warpframes, &ctx->acc, &ctx->scratch, &ctx->init_warps})
         b->release();
     keypoint_workspace_destroy(ctx->kp);
-    for (auto* k : ctx->kp_workers) keypoint_workspace_destroy(k);
-    for (auto ks : ctx->kp_streams) if (ks) (void)hipStreamDestroy(ks);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->prof_ev) if (e) (void)hipEventDestroy(e);
