@@ -270,8 +270,109 @@ __global__ __launch_bounds__(256) void gauss7_cols_kernel(const float* __restric
     dst[(size_t)y * w + x] = (uint8_t)min(max(r, 0), 255);
 }
 
+// Fused 7x7 blur: a 128 x 32 output tile per workgroup. The 8-bit source tile with its halo goes to LDS through
+// aligned dword loads (level rows are not dword-aligned in general: two aligned dwords + v_alignbyte give the four
+// bytes at any offset), the row pass writes an f32 tile to LDS, the column pass rounds to 8 bits. Same operation
+// order as the two-kernel form above (kept for images narrower than the halo), so the result is bit-identical.
+constexpr int G7_X = 128, G7_Y = 32, G7_HX = 4, G7_R = 3;
+constexpr int G7_TW = G7_X + 2 * G7_HX;              // 136 bytes per tile row
+constexpr int G7_TH = G7_Y + 2 * G7_R;               // 38 rows
+
+__device__ __forceinline__ uint32_t load4_unaligned(const uint8_t* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t lo = q[0];
+    if (sh == 0) return lo;
+    return __builtin_amdgcn_alignbyte(q[1], lo, sh);   // bytes sh .. sh+3 of the aligned pair
+}
+
+__global__ __launch_bounds__(256) void gauss7_fused_kernel(const uint8_t* __restrict__ src, int w, int h, Gauss7 k,
+                                                           uint8_t* __restrict__ dst, size_t pyr_stride) {
+    __shared__ __attribute__((aligned(16))) uint8_t T[G7_TH * G7_TW];
+    __shared__ __attribute__((aligned(16))) float R[G7_TH * G7_X];
+    src += blockIdx.z * pyr_stride; dst += blockIdx.z * pyr_stride;
+    const int x0 = blockIdx.x * G7_X, y0 = blockIdx.y * G7_Y;
+    const int tid = threadIdx.x;
+    // phase 1: source tile (+ halo) into LDS, 4 bytes per item
+    for (int i = tid; i < G7_TH * (G7_TW / 4); i += 256) {
+        const int ty = i / (G7_TW / 4), d = i - ty * (G7_TW / 4);
+        const int sy = refl101(y0 - G7_R + ty, h);
+        const int sx0 = x0 - G7_HX + 4 * d;
+        const uint8_t* row = src + (size_t)sy * w;
+        uint32_t v;
+        if (sx0 >= 0 && sx0 + 3 < w) v = load4_unaligned(row + sx0);
+        else {
+            v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v |= (uint32_t)row[refl101(sx0 + e, w)] << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(T + ty * G7_TW + 4 * d) = v;
+    }
+    __syncthreads();
+    // phase 2: row filter, 4 outputs per item: acc = k0 * s[x-3]; acc += k_i * s[x-3+i]
+    for (int i = tid; i < G7_TH * (G7_X / 4); i += 256) {
+        const int ty = i / (G7_X / 4), q = i - ty * (G7_X / 4);
+        const uint32_t* tp = reinterpret_cast<const uint32_t*>(T + ty * G7_TW + 4 * q);   // bytes 4q .. 4q+11; centre of e at 4q+4+e
+        const uint32_t d0 = tp[0], d1 = tp[1], d2 = tp[2];
+        float f[12];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            f[e] = (float)((d0 >> (8 * e)) & 255u); f[4 + e] = (float)((d1 >> (8 * e)) & 255u); f[8 + e] = (float)((d2 >> (8 * e)) & 255u);
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float acc = k.k[0] * f[1 + e];
+#pragma unroll
+            for (int t = 1; t < 7; t++) acc += k.k[t] * f[1 + e + t];
+            o[e] = acc;
+        }
+        *reinterpret_cast<float4*>(R + ty * G7_X + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // phase 3: column filter; thread = 4-wide strip x 4 output rows
+    {
+        const int strip = tid & 31, rg = tid >> 5;
+        float4 win[4 + 2 * G7_R];
+#pragma unroll
+        for (int t = 0; t < 4 + 2 * G7_R; t++) win[t] = *reinterpret_cast<const float4*>(R + (rg * 4 + t) * G7_X + 4 * strip);
+        const int x = x0 + 4 * strip;
+        const bool aligned = (w & 3) == 0;                 // then every row of the level is dword-aligned (level bases are)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int y = y0 + rg * 4 + e;
+            const float4 c = win[e + G7_R];
+            float4 acc = make_float4(k.k[3] * c.x, k.k[3] * c.y, k.k[3] * c.z, k.k[3] * c.w);
+#pragma unroll
+            for (int t = 1; t <= 3; t++) {
+                const float4 a = win[e + G7_R - t], b = win[e + G7_R + t];
+                acc.x += k.k[3 + t] * (a.x + b.x); acc.y += k.k[3 + t] * (a.y + b.y);
+                acc.z += k.k[3 + t] * (a.z + b.z); acc.w += k.k[3 + t] * (a.w + b.w);
+            }
+            if (y < h && x < w) {
+                const int r0 = min(max((int)__builtin_rintf(acc.x), 0), 255), r1 = min(max((int)__builtin_rintf(acc.y), 0), 255);
+                const int r2 = min(max((int)__builtin_rintf(acc.z), 0), 255), r3 = min(max((int)__builtin_rintf(acc.w), 0), 255);
+                uint8_t* op = dst + (size_t)y * w + x;
+                if (aligned && x + 3 < w) *reinterpret_cast<uint32_t*>(op) = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)r2 << 16) | ((uint32_t)r3 << 24);
+                else {
+                    op[0] = (uint8_t)r0;
+                    if (x + 1 < w) op[1] = (uint8_t)r1;
+                    if (x + 2 < w) op[2] = (uint8_t)r2;
+                    if (x + 3 < w) op[3] = (uint8_t)r3;
+                }
+            }
+        }
+    }
+}
+
 hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s,
                          int n_frames, size_t pyr_stride, size_t tmp_stride) {
+    if (w >= 8 && h >= 4 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (pyr_stride & 3) == 0) {
+        dim3 fgrid((w + G7_X - 1) / G7_X, (h + G7_Y - 1) / G7_Y, n_frames);
+        gauss7_fused_kernel<<<fgrid, 256, 0, s>>>(src, w, h, k, dst, pyr_stride);
+        return hipGetLastError();
+    }
     dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
     gauss7_rows_kernel<<<grid, 256, 0, s>>>(src, w, h, k, tmp, pyr_stride, tmp_stride);
     gauss7_cols_kernel<<<grid, 256, 0, s>>>(tmp, w, h, k, dst, pyr_stride, tmp_stride);

@@ -234,9 +234,9 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
 stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeometry& g, int n_frames = 1) {
     orb_geometry(w, h, g);
     const size_t F = (size_t)std::max(n_frames, 1);
-    HIP_TRY(ws->pyr.reserve(g.pyr.total * F));
-    HIP_TRY(ws->score.reserve(g.pyr.total * F));
-    HIP_TRY(ws->blur.reserve(g.pyr.total * F));
+    HIP_TRY(ws->pyr.reserve(g.pyr.total * F + 64));       // + slack: the tiled kernels read whole aligned dwords
+    HIP_TRY(ws->score.reserve(g.pyr.total * F + 64));
+    HIP_TRY(ws->blur.reserve(g.pyr.total * F + 64));
     HIP_TRY(ws->tmpf.reserve((size_t)w * h * sizeof(float) * F));
     HIP_TRY(ws->cand.reserve(g.cand_total * sizeof(OrbCandidate) * F));
     HIP_TRY(ws->sel.reserve(sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS * F));
