@@ -32,7 +32,7 @@ struct stk_ctx {
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
-    int opt_kp_workers = 8;       // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
+    int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 1152;    // total workgroups of one ECC iteration launch (all slots): more than the 768 the chip holds at
                                   // once, so the dispatcher balances the uneven rows-per-wave split (960 / 1344 measure worse)
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = row-factorised Hessian (homography, default), 0 = direct gathers,

@@ -96,7 +96,7 @@ def test_keypoint_1080p_oracle_and_ground_truth(stacker):
     try:
         d1, out1 = stacker.keypoint_match(frames, KP)
     finally:
-        stacker.set_option("kp_workers", 8)
+        stacker.set_option("kp_workers", 12)
     assert d1 == 0 and torch.equal(out, out1)
 
 
