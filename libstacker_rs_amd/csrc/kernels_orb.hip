@@ -15,6 +15,23 @@
 
 namespace stk {
 
+// ---- shared helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ int refl101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// four bytes at any address through aligned dword loads (level rows are not dword-aligned in general)
+__device__ __forceinline__ uint32_t load4_unaligned(const uint8_t* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t lo = q[0];
+    if (sh == 0) return lo;
+    return __builtin_amdgcn_alignbyte(q[1], lo, sh);   // bytes sh .. sh+3 of the aligned pair
+}
+
 // ---- pyramid ------------------------------------------------------------------------------------
 __device__ __forceinline__ void lin_coef(int d, int src, double scale, int& ofs, int& c0, int& c1) {
     const double fval = scale * ((double)d + 0.5) - 0.5;
@@ -115,18 +132,15 @@ hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* ds
 }
 
 // ---- FAST -----------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int stride, int thr) {
-    const int v = p[0];
-    // high-speed rejection: any 9 contiguous ring pixels contain at least two of the four compass points
-    const int n0 = v - p[3 * stride], n4 = v - p[3], n8 = v - p[-3 * stride], n12 = v - p[-3];
-    const int dark = (n0 > thr) + (n4 > thr) + (n8 > thr) + (n12 > thr);
-    const int bright = (n0 < -thr) + (n4 < -thr) + (n8 < -thr) + (n12 < -thr);
-    if (dark < 2 && bright < 2) return 0;
-    int d[16];
-    d[0] = n0;                       d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];   d[3] = v - p[stride + 3];
-    d[4] = n4;                       d[5] = v - p[-stride + 3];      d[6] = v - p[-2 * stride + 2];  d[7] = v - p[-3 * stride + 1];
-    d[8] = n8;                       d[9] = v - p[-3 * stride - 1];  d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
-    d[12] = n12;                     d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];  d[15] = v - p[3 * stride - 1];
+__device__ __forceinline__ void fast_ring(const uint8_t* __restrict__ p, int stride, int v, int (&d)[16]) {
+    d[0] = v - p[3 * stride];        d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];   d[3] = v - p[stride + 3];
+    d[4] = v - p[3];                 d[5] = v - p[-stride + 3];      d[6] = v - p[-2 * stride + 2];  d[7] = v - p[-3 * stride + 1];
+    d[8] = v - p[-3 * stride];       d[9] = v - p[-3 * stride - 1];  d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
+    d[12] = v - p[-3];               d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];  d[15] = v - p[3 * stride - 1];
+}
+
+// corner strength: the largest t for which the pixel is still a FAST-9 corner at threshold t (0 if none above thr)
+__device__ __forceinline__ int fast_strength(const int (&d)[16], int thr) {
     int best = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -136,6 +150,18 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int 
         best = max(best, max(mn, -mx));
     }
     return best > thr ? best - 1 : 0;
+}
+
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int stride, int thr) {
+    const int v = p[0];
+    // high-speed rejection: any 9 contiguous ring pixels contain at least two of the four compass points
+    const int n0 = v - p[3 * stride], n4 = v - p[3], n8 = v - p[-3 * stride], n12 = v - p[-3];
+    const int dark = (n0 > thr) + (n4 > thr) + (n8 > thr) + (n12 > thr);
+    const int bright = (n0 < -thr) + (n4 < -thr) + (n8 < -thr) + (n12 < -thr);
+    if (dark < 2 && bright < 2) return 0;
+    int d[16];
+    fast_ring(p, stride, v, d);
+    return fast_strength(d, thr);
 }
 
 // Batched over frames: blockIdx.z (or the named grid dimension) is the frame; per-frame arrays sit `*_stride`
@@ -150,6 +176,101 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
     int s = 0;
     if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) s = fast_score_at(img + (size_t)y * w + x, w, thr);
     score[(size_t)y * w + x] = (uint8_t)s;
+}
+
+// Tiled FAST score: a 128 x 32 pixel tile (+ 3 px halo) in LDS and three passes with workgroup-level compaction, so
+// that the expensive steps run on densely populated wavefronts instead of on every wavefront that contains one candidate:
+//   pass 1  every pixel: the 4-point compass pre-test (any 9-arc contains two of them)          -> list A (LDS)
+//   pass 2  list A: brighter / darker ring masks, 9-contiguous-bits test                           -> list B (corners)
+//   pass 3  list B: corner strength (min / max over the sixteen 9-arcs), written into an LDS score tile
+// The tile is then stored. Same score map as fast_score_kernel, which remains for tiny levels.
+constexpr int FT_X = 128, FT_Y = 32, FT_H = 3, FT_HX = 4;
+constexpr int FT_TW = FT_X + 2 * FT_HX;              // 136
+constexpr int FT_TH = FT_Y + 2 * FT_H;               // 38
+
+__device__ __forceinline__ bool has_arc9(uint32_t m) {          // 16-bit circular mask: 9 contiguous ones?
+    const uint32_t mm = m | (m << 16);                           // unrolled circle: bit k + 16 == bit k
+    const uint32_t a = mm & (mm >> 1), b = a & (a >> 2), c = b & (b >> 4);
+    return ((c & (mm >> 8)) & 0xffffu) != 0;
+}
+
+__global__ __launch_bounds__(256) void fast_score_tiled_kernel(const uint8_t* __restrict__ img, int w, int h, int thr,
+                                                               uint8_t* __restrict__ score, OrbBatch bs) {
+    __shared__ __attribute__((aligned(16))) uint8_t T[FT_TH * FT_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t S[FT_Y * FT_X];
+    __shared__ unsigned short listA[FT_X * FT_Y], listB[FT_X * FT_Y];
+    __shared__ int nA, nB;
+    img += blockIdx.z * bs.pyr; score += blockIdx.z * bs.pyr;
+    const int x0 = blockIdx.x * FT_X, y0 = blockIdx.y * FT_Y;
+    const int tid = threadIdx.x;
+    if (tid == 0) { nA = 0; nB = 0; }
+    for (int i = tid; i < FT_TH * (FT_TW / 4); i += 256) {
+        const int ty = i / (FT_TW / 4), d = i - ty * (FT_TW / 4);
+        const int sy = min(max(y0 - FT_H + ty, 0), h - 1);            // values outside the image are never used
+        const int sx0 = x0 - FT_HX + 4 * d;
+        const uint8_t* row = img + (size_t)sy * w;
+        uint32_t v = 0;
+        if (sx0 >= 0 && sx0 + 3 < w) v = load4_unaligned(row + sx0);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v |= (uint32_t)row[min(max(sx0 + e, 0), w - 1)] << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(T + ty * FT_TW + 4 * d) = v;
+    }
+    for (int i = tid; i < FT_X * FT_Y / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
+    __syncthreads();
+    // pass 1: compass pre-test
+    for (int i = tid; i < FT_X * FT_Y; i += 256) {
+        const int ty = i >> 7, tx = i & 127;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x < 3 || x >= w - 3 || y < 3 || y >= h - 3) continue;
+        const uint8_t* p = T + (ty + FT_H) * FT_TW + tx + FT_HX;
+        const int v = p[0];
+        const int n0 = v - p[3 * FT_TW], n4 = v - p[3], n8 = v - p[-3 * FT_TW], n12 = v - p[-3];
+        const int dark = (n0 > thr) + (n4 > thr) + (n8 > thr) + (n12 > thr);
+        const int bright = (n0 < -thr) + (n4 < -thr) + (n8 < -thr) + (n12 < -thr);
+        if (dark >= 2 || bright >= 2) listA[atomicAdd(&nA, 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+    // pass 2: ring masks, 9 contiguous
+    const int cntA = nA;
+    for (int i = tid; i < cntA; i += 256) {
+        const int id = listA[i], ty = id >> 7, tx = id & 127;
+        const uint8_t* p = T + (ty + FT_H) * FT_TW + tx + FT_HX;
+        int d[16];
+        fast_ring(p, FT_TW, (int)p[0], d);
+        uint32_t md = 0, mb = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { md |= (uint32_t)(d[k] > thr) << k; mb |= (uint32_t)(d[k] < -thr) << k; }
+        if (has_arc9(md) || has_arc9(mb)) listB[atomicAdd(&nB, 1)] = (unsigned short)id;
+    }
+    __syncthreads();
+    // pass 3: strength of the corners
+    const int cntB = nB;
+    for (int i = tid; i < cntB; i += 256) {
+        const int id = listB[i], ty = id >> 7, tx = id & 127;
+        const uint8_t* p = T + (ty + FT_H) * FT_TW + tx + FT_HX;
+        int d[16];
+        fast_ring(p, FT_TW, (int)p[0], d);
+        S[id] = (uint8_t)fast_strength(d, thr);
+    }
+    __syncthreads();
+    // store the score tile
+    const bool aligned = (w & 3) == 0;
+    for (int i = tid; i < FT_X * FT_Y / 4; i += 256) {
+        const int ty = i >> 5, q = i & 31;
+        const int x = x0 + 4 * q, y = y0 + ty;
+        if (y >= h || x >= w) continue;
+        const uint32_t v = reinterpret_cast<const uint32_t*>(S)[i];
+        uint8_t* op = score + (size_t)y * w + x;
+        if (aligned && x + 3 < w) *reinterpret_cast<uint32_t*>(op) = v;
+        else {
+            op[0] = (uint8_t)v;
+            if (x + 1 < w) op[1] = (uint8_t)(v >> 8);
+            if (x + 2 < w) op[2] = (uint8_t)(v >> 16);
+            if (x + 3 < w) op[3] = (uint8_t)(v >> 24);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, int w, int h, int edge,
@@ -227,8 +348,13 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
                              const OrbUmax& um, hipStream_t s, int n_frames, size_t pyr_stride, size_t states_stride,
                              size_t cand_stride, size_t sel_stride) {
     const OrbBatch bs{pyr_stride, states_stride, cand_stride, sel_stride};
-    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
-    fast_score_kernel<<<grid, 256, 0, s>>>(img, w, h, thr, score, bs);
+    if (w >= 16 && h >= 8 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 && (pyr_stride & 3) == 0) {
+        dim3 tgrid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, n_frames);
+        fast_score_tiled_kernel<<<tgrid, 256, 0, s>>>(img, w, h, thr, score, bs);
+    } else {
+        dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
+        fast_score_kernel<<<grid, 256, 0, s>>>(img, w, h, thr, score, bs);
+    }
     if (w > 2 * edge && h > 2 * edge) {
         dim3 g2((w - 2 * edge + 63) / 64, (h - 2 * edge + 3) / 4, n_frames);
         fast_nms_kernel<<<g2, 256, 0, s>>>(score, w, h, edge, st, cand, cap, bs);
@@ -239,12 +365,6 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
 }
 
 // ---- 7x7 Gaussian on 8-bit levels -----------------------------------------------------------------------
-__device__ __forceinline__ int refl101(int p, int len) {
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
-
 __global__ __launch_bounds__(256) void gauss7_rows_kernel(const uint8_t* __restrict__ src, int w, int h, Gauss7 k,
                                                           float* __restrict__ tmp, size_t pyr_stride, size_t tmp_stride) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -277,15 +397,6 @@ __global__ __launch_bounds__(256) void gauss7_cols_kernel(const float* __restric
 constexpr int G7_X = 128, G7_Y = 32, G7_HX = 4, G7_R = 3;
 constexpr int G7_TW = G7_X + 2 * G7_HX;              // 136 bytes per tile row
 constexpr int G7_TH = G7_Y + 2 * G7_R;               // 38 rows
-
-__device__ __forceinline__ uint32_t load4_unaligned(const uint8_t* p) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3);
-    const uint32_t lo = q[0];
-    if (sh == 0) return lo;
-    return __builtin_amdgcn_alignbyte(q[1], lo, sh);   // bytes sh .. sh+3 of the aligned pair
-}
 
 __global__ __launch_bounds__(256) void gauss7_fused_kernel(const uint8_t* __restrict__ src, int w, int h, Gauss7 k,
                                                            uint8_t* __restrict__ dst, size_t pyr_stride) {
