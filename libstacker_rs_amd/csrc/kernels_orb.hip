@@ -178,15 +178,19 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
     score[(size_t)y * w + x] = (uint8_t)s;
 }
 
-// Tiled FAST score: a 128 x 32 pixel tile (+ 3 px halo) in LDS and three passes with workgroup-level compaction, so
-// that the expensive steps run on densely populated wavefronts instead of on every wavefront that contains one candidate:
-//   pass 1  every pixel: the 4-point compass pre-test (any 9-arc contains two of them)          -> list A (LDS)
+// Tiled FAST + non-maximum suppression: a 128 x 32 pixel tile in LDS (4 px halo: 1 for the 3x3 NMS neighbourhood
+// + 3 for the ring) and three scoring passes with workgroup-level compaction, so that the expensive steps run on densely
+// populated wavefronts instead of on every wavefront that contains one candidate:
+//   pass 1  every pixel of the 130 x 34 score region: the 4-point compass pre-test              -> list A (LDS)
 //   pass 2  list A: brighter / darker ring masks, 9-contiguous-bits test                           -> list B (corners)
-//   pass 3  list B: corner strength (min / max over the sixteen 9-arcs), written into an LDS score tile
-// The tile is then stored. Same score map as fast_score_kernel, which remains for tiny levels.
-constexpr int FT_X = 128, FT_Y = 32, FT_H = 3, FT_HX = 4;
-constexpr int FT_TW = FT_X + 2 * FT_HX;              // 136
-constexpr int FT_TH = FT_Y + 2 * FT_H;               // 38
+//   pass 3  list B: corner strength (min / max over the sixteen 9-arcs) into an LDS score tile
+//   pass 4  the 128 x 32 interior: strict 3x3 maximum, runByImageBorder(edge), score histogram, candidate list
+// The score map never goes to memory. Same candidates and histogram as fast_score_kernel + fast_nms_kernel (kept for
+// tiny levels); the candidate ORDER differs (atomics), which the later stages do not depend on.
+constexpr int FT_X = 128, FT_Y = 32, FT_H = 4;
+constexpr int FT_TW = FT_X + 2 * FT_H;               // 136 bytes per image-tile row
+constexpr int FT_TH = FT_Y + 2 * FT_H;               // 40 rows
+constexpr int FT_SW = FT_X + 4, FT_SH = FT_Y + 2;    // score region 130 x 34, stored with a row stride of 132
 
 __device__ __forceinline__ bool has_arc9(uint32_t m) {          // 16-bit circular mask: 9 contiguous ones?
     const uint32_t mm = m | (m << 16);                           // unrolled circle: bit k + 16 == bit k
@@ -194,20 +198,20 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {          // 16-bit circul
     return ((c & (mm >> 8)) & 0xffffu) != 0;
 }
 
-__global__ __launch_bounds__(256) void fast_score_tiled_kernel(const uint8_t* __restrict__ img, int w, int h, int thr,
-                                                               uint8_t* __restrict__ score, OrbBatch bs) {
+__global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __restrict__ img, int w, int h, int thr, int edge,
+                                                             OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs) {
     __shared__ __attribute__((aligned(16))) uint8_t T[FT_TH * FT_TW];
-    __shared__ __attribute__((aligned(16))) uint8_t S[FT_Y * FT_X];
-    __shared__ unsigned short listA[FT_X * FT_Y], listB[FT_X * FT_Y];
+    __shared__ __attribute__((aligned(16))) uint8_t S[FT_SH * FT_SW];
+    __shared__ unsigned short listA[FT_SH * FT_SW], listB[FT_SH * FT_SW];
     __shared__ int nA, nB;
-    img += blockIdx.z * bs.pyr; score += blockIdx.z * bs.pyr;
+    img += blockIdx.z * bs.pyr; st += blockIdx.z * bs.states; cand += blockIdx.z * bs.cand;
     const int x0 = blockIdx.x * FT_X, y0 = blockIdx.y * FT_Y;
     const int tid = threadIdx.x;
     if (tid == 0) { nA = 0; nB = 0; }
     for (int i = tid; i < FT_TH * (FT_TW / 4); i += 256) {
         const int ty = i / (FT_TW / 4), d = i - ty * (FT_TW / 4);
         const int sy = min(max(y0 - FT_H + ty, 0), h - 1);            // values outside the image are never used
-        const int sx0 = x0 - FT_HX + 4 * d;
+        const int sx0 = x0 - FT_H + 4 * d;
         const uint8_t* row = img + (size_t)sy * w;
         uint32_t v = 0;
         if (sx0 >= 0 && sx0 + 3 < w) v = load4_unaligned(row + sx0);
@@ -217,26 +221,28 @@ __global__ __launch_bounds__(256) void fast_score_tiled_kernel(const uint8_t* __
         }
         *reinterpret_cast<uint32_t*>(T + ty * FT_TW + 4 * d) = v;
     }
-    for (int i = tid; i < FT_X * FT_Y / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
+    for (int i = tid; i < FT_SH * FT_SW / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
     __syncthreads();
+    // score-region pixel id = sy * FT_SW + sx, sx in [0, 130), sy in [0, 34); image pixel (x0 - 1 + sx, y0 - 1 + sy);
+    // its byte in T is at row sy + 3, column sx + 3
     // pass 1: compass pre-test
-    for (int i = tid; i < FT_X * FT_Y; i += 256) {
-        const int ty = i >> 7, tx = i & 127;
-        const int x = x0 + tx, y = y0 + ty;
+    for (int i = tid; i < FT_SH * (FT_X + 2); i += 256) {
+        const int sy = i / (FT_X + 2), sx = i - sy * (FT_X + 2);
+        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
         if (x < 3 || x >= w - 3 || y < 3 || y >= h - 3) continue;
-        const uint8_t* p = T + (ty + FT_H) * FT_TW + tx + FT_HX;
+        const uint8_t* p = T + (sy + 3) * FT_TW + sx + 3;
         const int v = p[0];
         const int n0 = v - p[3 * FT_TW], n4 = v - p[3], n8 = v - p[-3 * FT_TW], n12 = v - p[-3];
         const int dark = (n0 > thr) + (n4 > thr) + (n8 > thr) + (n12 > thr);
         const int bright = (n0 < -thr) + (n4 < -thr) + (n8 < -thr) + (n12 < -thr);
-        if (dark >= 2 || bright >= 2) listA[atomicAdd(&nA, 1)] = (unsigned short)i;
+        if (dark >= 2 || bright >= 2) listA[atomicAdd(&nA, 1)] = (unsigned short)(sy * FT_SW + sx);
     }
     __syncthreads();
     // pass 2: ring masks, 9 contiguous
     const int cntA = nA;
     for (int i = tid; i < cntA; i += 256) {
-        const int id = listA[i], ty = id >> 7, tx = id & 127;
-        const uint8_t* p = T + (ty + FT_H) * FT_TW + tx + FT_HX;
+        const int id = listA[i], sy = id / FT_SW, sx = id - sy * FT_SW;
+        const uint8_t* p = T + (sy + 3) * FT_TW + sx + 3;
         int d[16];
         fast_ring(p, FT_TW, (int)p[0], d);
         uint32_t md = 0, mb = 0;
@@ -248,27 +254,27 @@ __global__ __launch_bounds__(256) void fast_score_tiled_kernel(const uint8_t* __
     // pass 3: strength of the corners
     const int cntB = nB;
     for (int i = tid; i < cntB; i += 256) {
-        const int id = listB[i], ty = id >> 7, tx = id & 127;
-        const uint8_t* p = T + (ty + FT_H) * FT_TW + tx + FT_HX;
+        const int id = listB[i], sy = id / FT_SW, sx = id - sy * FT_SW;
+        const uint8_t* p = T + (sy + 3) * FT_TW + sx + 3;
         int d[16];
         fast_ring(p, FT_TW, (int)p[0], d);
         S[id] = (uint8_t)fast_strength(d, thr);
     }
     __syncthreads();
-    // store the score tile
-    const bool aligned = (w & 3) == 0;
-    for (int i = tid; i < FT_X * FT_Y / 4; i += 256) {
-        const int ty = i >> 5, q = i & 31;
-        const int x = x0 + 4 * q, y = y0 + ty;
-        if (y >= h || x >= w) continue;
-        const uint32_t v = reinterpret_cast<const uint32_t*>(S)[i];
-        uint8_t* op = score + (size_t)y * w + x;
-        if (aligned && x + 3 < w) *reinterpret_cast<uint32_t*>(op) = v;
-        else {
-            op[0] = (uint8_t)v;
-            if (x + 1 < w) op[1] = (uint8_t)(v >> 8);
-            if (x + 2 < w) op[2] = (uint8_t)(v >> 16);
-            if (x + 3 < w) op[3] = (uint8_t)(v >> 24);
+    // pass 4: strict 3x3 maxima of the interior -> histogram + candidate list (only corners can be maxima: walk list B)
+    for (int i = tid; i < cntB; i += 256) {
+        const int id = listB[i], sy = id / FT_SW, sx = id - sy * FT_SW;
+        if (sx < 1 || sx > FT_X || sy < 1 || sy > FT_Y) continue;     // halo pixel: another tile's interior
+        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
+        if (x < edge || x >= w - edge || y < edge || y >= h - edge) continue;
+        const uint8_t* c = S + id;
+        const int sc = c[0];
+        if (!sc) continue;
+        if (sc > c[-1] && sc > c[1] && sc > c[-FT_SW - 1] && sc > c[-FT_SW] && sc > c[-FT_SW + 1] && sc > c[FT_SW - 1] && sc > c[FT_SW] &&
+            sc > c[FT_SW + 1]) {
+            atomicAdd(&st->hist[sc], 1);
+            const int o = atomicAdd(&st->n_cand, 1);
+            if (o < cap) { cand[o].xy = x | (y << 16); cand[o].score = sc; }
         }
     }
 }
@@ -305,13 +311,12 @@ __global__ __launch_bounds__(64) void fast_select_kernel(const uint8_t* __restri
                                                          OrbLevelState* st, const OrbCandidate* __restrict__ cand,
                                                          int cap, OrbSelected* sel, int sel_cap, OrbUmax um, OrbBatch bs) {
     img += blockIdx.y * bs.pyr; st += blockIdx.y * bs.states; cand += blockIdx.y * bs.cand; sel += blockIdx.y * bs.sel;
-    const int i = blockIdx.x * 64 + threadIdx.x;
     const int n = min(st->n_cand, cap);
-    if (i >= n) return;
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {      // a few thousand candidates at most
     const OrbCandidate c = cand[i];
-    if (c.score < st->threshold) return;
+    if (c.score < st->threshold) continue;
     const int o = atomicAdd(&st->n_sel, 1);
-    if (o >= sel_cap) return;
+    if (o >= sel_cap) continue;
     const int x = c.xy & 0xffff, y = c.xy >> 16;
     const uint8_t* p0 = img + (size_t)y * w + x;
     int a = 0, b = 0, cc = 0;
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(64) void fast_select_kernel(const uint8_t* __restri
     OrbSelected s;
     s.xy = c.xy; s.score = c.score; s.harris = resp; s.m01 = m01; s.m10 = m10;
     sel[o] = s;
+  }
 }
 
 hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
@@ -349,18 +355,20 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
                              size_t cand_stride, size_t sel_stride) {
     const OrbBatch bs{pyr_stride, states_stride, cand_stride, sel_stride};
     if (w >= 16 && h >= 8 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 && (pyr_stride & 3) == 0) {
-        dim3 tgrid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, n_frames);
-        fast_score_tiled_kernel<<<tgrid, 256, 0, s>>>(img, w, h, thr, score, bs);
+        if (w > 2 * edge && h > 2 * edge) {               // otherwise runByImageBorder leaves nothing: no candidates at all
+            dim3 tgrid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, n_frames);
+            fast_nms_tiled_kernel<<<tgrid, 256, 0, s>>>(img, w, h, thr, edge, st, cand, cap, bs);
+        }
     } else {
         dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
         fast_score_kernel<<<grid, 256, 0, s>>>(img, w, h, thr, score, bs);
-    }
-    if (w > 2 * edge && h > 2 * edge) {
-        dim3 g2((w - 2 * edge + 63) / 64, (h - 2 * edge + 3) / 4, n_frames);
-        fast_nms_kernel<<<g2, 256, 0, s>>>(score, w, h, edge, st, cand, cap, bs);
+        if (w > 2 * edge && h > 2 * edge) {
+            dim3 g2((w - 2 * edge + 63) / 64, (h - 2 * edge + 3) / 4, n_frames);
+            fast_nms_kernel<<<g2, 256, 0, s>>>(score, w, h, edge, st, cand, cap, bs);
+        }
     }
     fast_threshold_kernel<<<n_frames, 64, 0, s>>>(st, keep, bs);
-    fast_select_kernel<<<dim3((cap + 63) / 64, n_frames), 64, 0, s>>>(img, w, h, st, cand, cap, sel, sel_cap, um, bs);
+    fast_select_kernel<<<dim3(std::min((cap + 63) / 64, 64), n_frames), 64, 0, s>>>(img, w, h, st, cand, cap, sel, sel_cap, um, bs);
     return hipGetLastError();
 }
 
