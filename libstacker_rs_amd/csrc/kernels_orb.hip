@@ -6,7 +6,7 @@
 //   fast_score     FAST-9/16 corner strength per pixel (0 = not a corner at the threshold)
 //   fast_nms       3x3 strict non-maximum suppression + runByImageBorder(31) + score histogram + collect
 //   fast_threshold per level: the score of the (2 n_l)-th best corner (retainBest keeps ties)
-//   fast_select    candidates >= threshold -> short list, with Harris response and the IC moments
+//   fast_pick / fast_describe   candidates >= threshold -> short list; Harris response and IC moments, a wave per corner
 //   gauss7_rows/cols  GaussianBlur 7x7 sigma 2 (float separable filter, cvRound to u8)
 //   brief          rotated BRIEF, 256 tests, one lane per descriptor byte
 //   knn2_hamming   popcount(xor) over 32 B, two best train rows per query, ties keep the lower index
@@ -306,47 +306,63 @@ __global__ void fast_threshold_kernel(OrbLevelState* st, int keep, OrbBatch bs) 
     st->n_sel = 0;
 }
 
-// Harris response (blockSize 7, Sobel-like 3x3 on the 8-bit level, integer sums) and the IC moments
-__global__ __launch_bounds__(64) void fast_select_kernel(const uint8_t* __restrict__ img, int w, int h,
-                                                         OrbLevelState* st, const OrbCandidate* __restrict__ cand,
-                                                         int cap, OrbSelected* sel, int sel_cap, OrbUmax um, OrbBatch bs) {
-    img += blockIdx.y * bs.pyr; st += blockIdx.y * bs.states; cand += blockIdx.y * bs.cand; sel += blockIdx.y * bs.sel;
+// Short list: candidates >= threshold, then the Harris response (blockSize 7, Sobel-like 3x3 on the 8-bit level,
+// integer sums) and the IC moments of each. Two kernels: fast_pick compacts (cheap, one lane per candidate), then
+// fast_describe gives every short-listed corner a whole wavefront — its 49 Harris positions and 31 patch rows are
+// spread over the lanes and reduced with integer adds, which are exact in any order (same values as a serial loop).
+__global__ __launch_bounds__(64) void fast_pick_kernel(OrbLevelState* st, const OrbCandidate* __restrict__ cand, int cap,
+                                                       OrbSelected* sel, int sel_cap, OrbBatch bs) {
+    st += blockIdx.y * bs.states; cand += blockIdx.y * bs.cand; sel += blockIdx.y * bs.sel;
     const int n = min(st->n_cand, cap);
-  for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {      // a few thousand candidates at most
-    const OrbCandidate c = cand[i];
-    if (c.score < st->threshold) continue;
-    const int o = atomicAdd(&st->n_sel, 1);
-    if (o >= sel_cap) continue;
-    const int x = c.xy & 0xffff, y = c.xy >> 16;
-    const uint8_t* p0 = img + (size_t)y * w + x;
-    int a = 0, b = 0, cc = 0;
-    for (int dy = -3; dy <= 3; dy++)
-        for (int dx = -3; dx <= 3; dx++) {
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+        const OrbCandidate c = cand[i];
+        if (c.score < st->threshold) continue;
+        const int o = atomicAdd(&st->n_sel, 1);
+        if (o < sel_cap) { sel[o].xy = c.xy; sel[o].score = c.score; }
+    }
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void fast_describe_kernel(const uint8_t* __restrict__ img, int w, const OrbLevelState* st,
+                                                            OrbSelected* sel, int sel_cap, OrbUmax um, OrbBatch bs) {
+    img += blockIdx.y * bs.pyr; st += blockIdx.y * bs.states; sel += blockIdx.y * bs.sel;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = min(st->n_sel, sel_cap);
+    for (int o = blockIdx.x * 4 + wave; o < n; o += gridDim.x * 4) {
+        const int xy = sel[o].xy, x = xy & 0xffff, y = xy >> 16;
+        const uint8_t* p0 = img + (size_t)y * w + x;
+        int a = 0, b = 0, cc = 0;
+        if (lane < 49) {
+            const int dy = lane / 7 - 3, dx = lane % 7 - 3;
             const uint8_t* p = p0 + dy * w + dx;
             const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-w + 1] - (int)p[-w - 1]) + ((int)p[w + 1] - (int)p[w - 1]);
             const int Iy = ((int)p[w] - (int)p[-w]) * 2 + ((int)p[w - 1] - (int)p[-w - 1]) + ((int)p[w + 1] - (int)p[-w + 1]);
-            a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
+            a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
         }
-    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-    const float scale4 = scale * scale * scale * scale;
-    const float fa = (float)a, fb = (float)b, fc = (float)cc;
-    const float resp = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale4;
-    int m01 = 0, m10 = 0;
-    for (int u = -15; u <= 15; u++) m10 += u * (int)p0[u];
-    for (int v = 1; v <= 15; v++) {
-        int vsum = 0;
-        const int d = um.u[v];
-        for (int u = -d; u <= d; u++) {
-            const int vp = p0[u + v * w], vm = p0[u - v * w];
-            vsum += vp - vm;
-            m10 += u * (vp + vm);
+        a = wave_sum_i32(a); b = wave_sum_i32(b); cc = wave_sum_i32(cc);
+        // IC moments over the circular patch: lane = row v in [-15, 15]
+        int m01 = 0, m10 = 0;
+        if (lane < 31) {
+            const int v = lane - 15, d = um.u[v < 0 ? -v : v];
+            const uint8_t* row = p0 + v * w;
+            int rs = 0;
+            for (int u = -d; u <= d; u++) { const int px = row[u]; m10 += u * px; rs += px; }
+            m01 = v * rs;
         }
-        m01 += v * vsum;
+        m01 = wave_sum_i32(m01); m10 = wave_sum_i32(m10);
+        if (lane == 0) {
+            const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+            const float scale4 = scale * scale * scale * scale;
+            const float fa = (float)a, fb = (float)b, fc = (float)cc;
+            sel[o].harris = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale4;
+            sel[o].m01 = m01; sel[o].m10 = m10;
+        }
     }
-    OrbSelected s;
-    s.xy = c.xy; s.score = c.score; s.harris = resp; s.m01 = m01; s.m10 = m10;
-    sel[o] = s;
-  }
 }
 
 hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
@@ -368,7 +384,8 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
         }
     }
     fast_threshold_kernel<<<n_frames, 64, 0, s>>>(st, keep, bs);
-    fast_select_kernel<<<dim3(std::min((cap + 63) / 64, 64), n_frames), 64, 0, s>>>(img, w, h, st, cand, cap, sel, sel_cap, um, bs);
+    fast_pick_kernel<<<dim3(std::min((cap + 63) / 64, 64), n_frames), 64, 0, s>>>(st, cand, cap, sel, sel_cap, bs);
+    fast_describe_kernel<<<dim3(128, n_frames), 256, 0, s>>>(img, w, st, sel, sel_cap, um, bs);
     return hipGetLastError();
 }
 
