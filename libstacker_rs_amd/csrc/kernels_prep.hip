@@ -27,11 +27,13 @@ __device__ __forceinline__ float grey_f32(float b, float g, float r) {
     return b * 0.114f + g * 0.587f + r * 0.299f;   // -ffp-contract=off: three roundings, as the oracle
 }
 
+// blockIdx.z = frame of a batch: source frames `src_frame_stride` elements apart, outputs `out_frame_stride` apart
 template <typename T>
 __global__ __launch_bounds__(256) void grey_kernel(const T* __restrict__ src, size_t stride, int w, int h,
-                                                   T* __restrict__ out) {
+                                                   T* __restrict__ out, size_t src_frame_stride, size_t out_frame_stride) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    src += blockIdx.z * src_frame_stride; out += blockIdx.z * out_frame_stride;
     const T* p = src + (size_t)y * stride + (size_t)x * 3;
     T v;
     if constexpr (sizeof(T) == 1) v = grey_u8(p[0], p[1], p[2]);
@@ -40,11 +42,13 @@ __global__ __launch_bounds__(256) void grey_kernel(const T* __restrict__ src, si
     out[(size_t)y * w + x] = v;
 }
 
-hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void* out, hipStream_t s) {
-    dim3 grid((w + 255) / 256, h);
-    if (depth == 8) grey_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)bgr, stride_bytes, w, h, (uint8_t*)out);
-    else if (depth == 16) grey_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)bgr, stride_bytes / 2, w, h, (uint16_t*)out);
-    else grey_kernel<float><<<grid, 256, 0, s>>>((const float*)bgr, stride_bytes / 4, w, h, (float*)out);
+// n_frames > 1: frames `src_frame_bytes` apart in memory, grey images `out_frame_elems` elements apart
+hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void* out, hipStream_t s,
+                       int n_frames, size_t src_frame_bytes, size_t out_frame_elems) {
+    dim3 grid((w + 255) / 256, h, n_frames);
+    if (depth == 8) grey_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)bgr, stride_bytes, w, h, (uint8_t*)out, src_frame_bytes, out_frame_elems);
+    else if (depth == 16) grey_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)bgr, stride_bytes / 2, w, h, (uint16_t*)out, src_frame_bytes / 2, out_frame_elems);
+    else grey_kernel<float><<<grid, 256, 0, s>>>((const float*)bgr, stride_bytes / 4, w, h, (float*)out, src_frame_bytes / 4, out_frame_elems);
     return hipGetLastError();
 }
 

@@ -423,8 +423,14 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     // independent of the others (lib.rs:185-290 is the body of a Rayon map).
     for (int b0 = 0; b0 < n; b0 += batch) {
         const int nb = std::min(batch, n - b0);
-        for (int k = 0; k < nb; k++)
-            if ((st = grey_level0(dev[b0 + k], k))) return st;
+        // level 0 of every pyramid of the batch: one launch when the frames are evenly spaced in memory (a tensor), else per frame
+        bool even = !scaled && nb > 1;
+        const ptrdiff_t fstep = nb > 1 ? (const uint8_t*)dev[b0 + 1] - (const uint8_t*)dev[b0] : 0;
+        for (int k = 1; even && k + 1 < nb; k++) even = ((const uint8_t*)dev[b0 + k + 1] - (const uint8_t*)dev[b0 + k]) == fstep;
+        if (even && fstep > 0) HIP_TRY(launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total));
+        else
+            for (int k = 0; k < nb; k++)
+                if ((st = grey_level0(dev[b0 + k], k))) return st;
         std::vector<std::vector<HostKeypoint>> kps;
         if ((st = orb_run(ctx, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps))) return st;   // ends synchronised
         int first = 0;                                         // first moving frame of this batch
