@@ -42,9 +42,30 @@ __global__ __launch_bounds__(256) void grey_kernel(const T* __restrict__ src, si
     out[(size_t)y * w + x] = v;
 }
 
+// 8-bit fast path: four pixels per lane from three aligned dwords, one dword store (rows and outputs 4-byte aligned)
+__global__ __launch_bounds__(256) void grey_u8x4_kernel(const uint8_t* __restrict__ src, size_t stride, int w, int h,
+                                                        uint8_t* __restrict__ out, size_t src_frame_stride, size_t out_frame_stride) {
+    const int q = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (q * 4 >= w) return;
+    src += blockIdx.z * src_frame_stride; out += blockIdx.z * out_frame_stride;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (size_t)y * stride + (size_t)q * 12);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+    const uint32_t g0 = grey_u8(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u);
+    const uint32_t g1 = grey_u8(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u);
+    const uint32_t g2 = grey_u8((d1 >> 16) & 255u, d1 >> 24, d2 & 255u);
+    const uint32_t g3 = grey_u8((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24);
+    *reinterpret_cast<uint32_t*>(out + (size_t)y * w + (size_t)q * 4) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+}
+
 // n_frames > 1: frames `src_frame_bytes` apart in memory, grey images `out_frame_elems` elements apart
 hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void* out, hipStream_t s,
                        int n_frames, size_t src_frame_bytes, size_t out_frame_elems) {
+    if (depth == 8 && w % 4 == 0 && stride_bytes % 4 == 0 && src_frame_bytes % 4 == 0 && out_frame_elems % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(bgr) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        dim3 g4((w / 4 + 255) / 256, h, n_frames);
+        grey_u8x4_kernel<<<g4, 256, 0, s>>>((const uint8_t*)bgr, stride_bytes, w, h, (uint8_t*)out, src_frame_bytes, out_frame_elems);
+        return hipGetLastError();
+    }
     dim3 grid((w + 255) / 256, h, n_frames);
     if (depth == 8) grey_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)bgr, stride_bytes, w, h, (uint8_t*)out, src_frame_bytes, out_frame_elems);
     else if (depth == 16) grey_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)bgr, stride_bytes / 2, w, h, (uint16_t*)out, src_frame_bytes / 2, out_frame_elems);
