@@ -45,6 +45,7 @@ struct stk_ctx {
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
     stk::KeypointWorkspace* kp = nullptr;
+    stk::HostPool* host_pool = nullptr;   // persistent host threads of the keypoint path (keypoint.cpp)
     std::mutex err_mutex;
 };
 

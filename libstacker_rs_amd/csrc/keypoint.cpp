@@ -13,6 +13,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "context.h"
@@ -124,16 +127,84 @@ void retain_best(std::vector<T>& v, int n, F resp) {
 constexpr size_t MAX_KP = 4096;   // descriptor rows per frame (500 + ties)
 constexpr int ORB_PACK = 512;     // short-list entries per level fetched in the one strided copy (2 n_l + ties fit; else a 2nd copy)
 
-// run `fn(i)` for i in [0, n) on up to `threads` host threads (pure host work: no HIP calls inside)
+}  // namespace
+
+namespace stk {
+
+// A small persistent pool for the per-frame host steps (spawning 12 threads twice per stack cost ~0.5 ms of a 6 ms stack).
+class HostPool {
+public:
+    explicit HostPool(int n) {
+        for (int i = 0; i < n; i++) workers_.emplace_back([this]() { loop(); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size(); }
+    // run fn(i) for i in [0, n); the calling thread takes part; returns when all are done
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_ = n; next_.store(0); pending_ = n; gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
+void host_pool_destroy(HostPool* p) { delete p; }
+
+}  // namespace stk
+
+namespace {
+
+// run `fn(i)` for i in [0, n) on the context's host pool (pure host work: no HIP calls inside)
 template <typename F>
-void parallel_for(int n, int threads, F fn) {
-    threads = std::max(1, std::min(threads, n));
-    if (threads == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++)
-        pool.emplace_back([&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i); } });
-    for (auto& t : pool) t.join();
+void parallel_for(stk_ctx* ctx, int n, int threads, F fn) {
+    if (threads <= 1 || n <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    if (!ctx->host_pool || ctx->host_pool->size() != threads - 1) {
+        host_pool_destroy(ctx->host_pool);
+        ctx->host_pool = new HostPool(threads - 1);          // the caller is the remaining thread
+    }
+    const std::function<void(int)> f = fn;
+    ctx->host_pool->run(n, f);
 }
 
 // ORB on `n_frames` 8-bit grey images that already sit in level 0 of the workspace pyramids (frame f at
@@ -180,7 +251,7 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
 
     out.assign(n_frames, {});
     std::vector<std::vector<OrbFinalKeypoint>> fins(n_frames);
-    parallel_for(n_frames, threads, [&](int f) {
+    parallel_for(ctx, n_frames, threads, [&](int f) {
         std::vector<HostKeypoint>& o = out[f];
         std::vector<OrbFinalKeypoint>& fin = fins[f];
         for (int l = 0; l < ORB_LEVELS; l++) {
@@ -454,7 +525,7 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
             HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
-        parallel_for(n_mov, threads, [&](int m) {
+        parallel_for(ctx, n_mov, threads, [&](int m) {
             const int i = b0 + first + m;
             const std::vector<HostKeypoint>& kp = kps[first + m];
             FrameResult& R = results[i];

@@ -19,6 +19,8 @@ struct OrbPyramid { int w[ORB_LEVELS], h[ORB_LEVELS]; size_t ofs[ORB_LEVELS]; si
 struct OrbFinalKeypoint { int level, cx, cy; float cos_a, sin_a; int frame, row; };   // row: descriptor row to write
 
 struct KeypointWorkspace;
+class HostPool;
+void host_pool_destroy(HostPool*);
 KeypointWorkspace* keypoint_workspace_create();
 void keypoint_workspace_destroy(KeypointWorkspace*);
 

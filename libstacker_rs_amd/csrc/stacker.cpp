@@ -94,6 +94,7 @@ void stk_destroy(stk_ctx* ctx) {
                       &ctx->partials, &ctx->warpframes, &ctx->acc, &ctx->scratch, &ctx->init_warps})
         b->release();
     keypoint_workspace_destroy(ctx->kp);
+    host_pool_destroy(ctx->host_pool);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->prof_ev) if (e) (void)hipEventDestroy(e);
