@@ -184,6 +184,20 @@ stk_status stk_grey(stk_ctx* ctx, const stk_frames* frame /* n==1 */, void* out)
 /* Mat::convert_to(CV_32F, alpha) utils.rs:133 (alpha = 1/255 there). */
 stk_status stk_convert_f32(stk_ctx* ctx, const stk_frames* frame /* n==1 */, double alpha,
                            float* out);
+/* ---- file front-end ---------------------------------------------------------
+ * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit): BGR or grey
+ * rows, tightly packed, into `data` (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.
+ * Formats that need an external codec (JPEG, PNG, TIFF ...) -> STK_NOT_IMPLEMENTED; unreadable / not an image ->
+ * STK_BACKEND_ERROR, as the reference's empty Mat + cvtColor does. */
+stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width,
+                      int32_t* height, int32_t* channels, int32_t* depth);
+/* keypoint_match / ecc_match in the reference's own call shape: a list of file paths, first = reference frame
+ * (lib.rs:129-137, 702-710). `out` is a host or device image as for the frame-based entry points. */
+stk_status stk_keypoint_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_keypoint_params* params,
+                                    float scale_down_width, stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats);
+stk_status stk_ecc_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_ecc_params* params,
+                               float scale_down_width, stk_image_f32* out, stk_frame_stats* stats);
+
 /* sharpness_modified_laplacian / _variance_of_laplacian / _tenengrad(k_size) / _normalized_gray_level_variance
  * (lib.rs:1030-1166; the pre-filter of examples/main.rs:40-47) of a single-channel 8-bit or f32 image, tightly packed.
  * `ksize` is read by TENG only (1, 3, 5 or 7, else STK_INVALID_PARAMS like lib.rs:1105). */

@@ -13,6 +13,7 @@ marshals pointers; it has no CPU fallback and raises if the library is missing.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import enum
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
@@ -333,6 +334,55 @@ class Stacker:
             out = np.empty(m.keep[0].shape, np.float32)
             ptr = out.ctypes.data
         self._check(self._lib.stk_convert_f32(self._h, C.byref(m.c_frames), float(alpha), C.c_void_p(ptr)))
+        return out
+
+    # -- file front-end: the reference's entry points take paths ------------------------------
+    def imread(self, path):
+        """imgcodecs::imread(path, IMREAD_UNCHANGED) for binary PNM (P5 / P6, 8 or 16 bit): HxW or HxWx3 (BGR) array."""
+        w, h, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        bp = os.fsencode(path)
+        self._check(self._lib.stk_imread(self._h, bp, None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)))
+        out = np.empty((h.value, w.value, c.value), np.uint8 if d.value == 8 else np.uint16)
+        self._check(self._lib.stk_imread(self._h, bp, C.c_void_p(out.ctypes.data), out.nbytes, None, None, None, None))
+        return out[..., 0] if c.value == 1 else out
+
+    def _paths(self, files):
+        enc = [os.fsencode(f) for f in files]
+        arr = (C.c_char_p * max(len(enc), 1))(*enc)
+        return enc, arr
+
+    def _file_geometry(self, files):
+        w, h, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.stk_imread(self._h, os.fsencode(files[0]), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)))
+        return w.value, h.value
+
+    def keypoint_match_files(self, files, params: KeyPointMatchParameters, scale_down_width: Optional[float] = None):
+        """keypoint_match(files, params, scale_down_width) -> (dropped, HxWx3 f32)   lib.rs:129-137"""
+        files = list(files)
+        if not files:
+            raise NotEnoughFiles("Not enough files")
+        w, h = self._file_geometry(files)
+        out = np.empty((h, w, 3), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w, h, 3, HOST, 0)
+        keep, arr = self._paths(files)
+        dropped = C.c_int32(0)
+        p = params._c()
+        self._check(self._lib.stk_keypoint_match_files(self._h, arr, len(files), C.byref(p), float(scale_down_width or 0.0),
+                                                       C.byref(img), C.byref(dropped), None))
+        return dropped.value, out
+
+    def ecc_match_files(self, files, params: EccMatchParameters, scale_down_width: Optional[float] = None):
+        """ecc_match(files, params, scale_down_width) -> HxWx3 f32   lib.rs:702-710"""
+        files = list(files)
+        if not files:
+            raise NotEnoughFiles("Not enough files")
+        w, h = self._file_geometry(files)
+        out = np.empty((h, w, 3), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w, h, 3, HOST, 0)
+        keep, arr = self._paths(files)
+        p = params._c()
+        self._check(self._lib.stk_ecc_match_files(self._h, arr, len(files), C.byref(p), float(scale_down_width or 0.0),
+                                                  C.byref(img), None))
         return out
 
     def _sharpness(self, grey, metric: int, ksize: int = 0) -> float:

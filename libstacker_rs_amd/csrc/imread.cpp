@@ -1,0 +1,155 @@
+// imread.cpp — the file front-end of the reference's entry points: `imgcodecs::imread(path,
+// IMREAD_UNCHANGED)` (utils.rs:110-117, 132) for the one family of formats this build can decode without external codec
+// libraries — binary PNM (P5 grey, P6 colour; 8 or 16 bit) — and keypoint_match / ecc_match in the reference's own call
+// shape, a list of paths (lib.rs:129-137, 702-710). JPEG / PNG / TIFF need libjpeg / libpng / libtiff, whose headers
+// are not in this image: those paths return STK_NOT_IMPLEMENTED and the caller decodes them itself (the frame-based
+// entry points are the boundary). A file that is missing or not an image behaves as in the reference: imread gives an
+// empty Mat and the following cvtColor raises -> STK_BACKEND_ERROR (OpenCvError).
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "context.h"
+
+namespace {
+
+struct Pnm { int w = 0, h = 0, cn = 0, depth = 0; size_t data_ofs = 0; };
+
+// parse "P5|P6 <w> <h> <maxval>\n" with '#' comments; returns 0 ok, 1 not a PNM, 2 unsupported variant
+int pnm_header(const unsigned char* b, size_t n, Pnm& p) {
+    if (n < 3 || b[0] != 'P' || (b[1] != '5' && b[1] != '6')) return 1;
+    p.cn = b[1] == '6' ? 3 : 1;
+    size_t i = 2;
+    long v[3];
+    for (int k = 0; k < 3; k++) {
+        for (;;) {                                            // whitespace and comments
+            while (i < n && (b[i] == ' ' || b[i] == '\t' || b[i] == '\n' || b[i] == '\r')) i++;
+            if (i < n && b[i] == '#') { while (i < n && b[i] != '\n') i++; continue; }
+            break;
+        }
+        if (i >= n || b[i] < '0' || b[i] > '9') return 1;
+        long x = 0;
+        while (i < n && b[i] >= '0' && b[i] <= '9') { x = x * 10 + (b[i] - '0'); if (x > 1000000) return 1; i++; }
+        v[k] = x;
+    }
+    if (i >= n) return 1;
+    i++;                                                      // the single whitespace byte before the raster
+    if (v[0] <= 0 || v[1] <= 0) return 1;
+    if (v[2] != 255 && v[2] != 65535) return 2;               // other maxvals: OpenCV's handling is not restated here
+    p.w = (int)v[0]; p.h = (int)v[1]; p.depth = v[2] == 255 ? 8 : 16; p.data_ofs = i;
+    return 0;
+}
+
+bool read_file(const char* path, std::vector<unsigned char>& out) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz < 0) { std::fclose(f); return false; }
+    out.resize((size_t)sz);
+    const size_t got = sz ? std::fread(out.data(), 1, (size_t)sz, f) : 0;
+    std::fclose(f);
+    return got == (size_t)sz;
+}
+
+bool has_ext(const char* path, const char* ext) {
+    const size_t lp = std::strlen(path), le = std::strlen(ext);
+    if (lp < le) return false;
+    for (size_t i = 0; i < le; i++) {
+        char c = path[lp - le + i];
+        if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+        if (c != ext[i]) return false;
+    }
+    return true;
+}
+
+// decode into `dst` (w*h*cn samples of depth/8 bytes): RGB -> BGR, 16-bit big-endian -> native
+void pnm_decode(const unsigned char* raster, const Pnm& p, void* dst) {
+    const size_t px = (size_t)p.w * p.h;
+    if (p.depth == 8) {
+        unsigned char* o = (unsigned char*)dst;
+        if (p.cn == 1) std::memcpy(o, raster, px);
+        else for (size_t i = 0; i < px; i++) { o[3 * i] = raster[3 * i + 2]; o[3 * i + 1] = raster[3 * i + 1]; o[3 * i + 2] = raster[3 * i]; }
+    } else {
+        unsigned short* o = (unsigned short*)dst;
+        auto be = [&](size_t s) { return (unsigned short)((raster[2 * s] << 8) | raster[2 * s + 1]); };
+        if (p.cn == 1) for (size_t i = 0; i < px; i++) o[i] = be(i);
+        else for (size_t i = 0; i < px; i++) { o[3 * i] = be(3 * i + 2); o[3 * i + 1] = be(3 * i + 1); o[3 * i + 2] = be(3 * i); }
+    }
+}
+
+// 0 ok; else a status with the message set
+stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>& file, Pnm& p) {
+    if (!path) return fail(ctx, STK_INVALID_PARAMS, "null path");
+    for (const char* e : {".jpg", ".jpeg", ".jpe", ".png", ".tif", ".tiff", ".bmp", ".webp", ".exr"})
+        if (has_ext(path, e))
+            return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: no codec for '") + path + "' in this build (binary PNM only); decode it "
+                                                  "on the caller's side and use the frame-based entry points");
+    if (!read_file(path, file)) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot read '") + path + "' (empty Mat -> cvtColor fails)");
+    const int rc = pnm_header(file.data(), file.size(), p);
+    if (rc == 2) return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: PNM maxval other than 255 / 65535 in '") + path + "'");
+    if (rc != 0) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: '") + path + "' is not an image this build can decode");
+    const size_t need = (size_t)p.w * p.h * p.cn * (p.depth / 8);
+    if (file.size() - p.data_ofs < need) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: '") + path + "' is truncated");
+    return STK_OK;
+}
+
+template <typename Call>
+stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call call) {
+    if (!ctx) return STK_INVALID_PARAMS;
+    if (n <= 0 || !paths) return fail(ctx, STK_NOT_ENOUGH_FILES, "Not enough files");      // lib.rs:155-157, 725-727
+    std::vector<std::vector<unsigned char>> pix(n);
+    std::vector<void*> ptrs(n);
+    Pnm first;
+    for (int i = 0; i < n; i++) {
+        std::vector<unsigned char> file;
+        Pnm p;
+        stk_status st = load_image(ctx, paths[i], file, p);
+        if (st) return st;
+        if (i == 0) first = p;
+        else if (p.w != first.w || p.h != first.h || p.cn != first.cn || p.depth != first.depth)
+            return fail(ctx, STK_INVALID_PARAMS, std::string("'") + paths[i] + "' differs in size or type from the first frame");
+        pix[i].resize((size_t)p.w * p.h * p.cn * (p.depth / 8));
+        pnm_decode(file.data() + p.data_ofs, p, pix[i].data());
+        ptrs[i] = pix[i].data();
+    }
+    stk_frames fr{};
+    fr.data = ptrs.data(); fr.n = n; fr.width = first.w; fr.height = first.h; fr.channels = first.cn; fr.depth = first.depth;
+    fr.location = STK_HOST; fr.row_stride_bytes = 0;
+    return call(&fr);
+}
+
+}  // namespace
+
+extern "C" {
+
+stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width, int32_t* height,
+                      int32_t* channels, int32_t* depth) {
+    std::vector<unsigned char> file;
+    Pnm p;
+    stk_status st = load_image(ctx, path, file, p);
+    if (st) return st;
+    if (width) *width = p.w;
+    if (height) *height = p.h;
+    if (channels) *channels = p.cn;
+    if (depth) *depth = p.depth;
+    if (!data) return STK_OK;                                  // geometry query
+    const size_t need = (size_t)p.w * p.h * p.cn * (p.depth / 8);
+    if (capacity_bytes < need) return fail(ctx, STK_INVALID_PARAMS, "imread: output buffer too small");
+    pnm_decode(file.data() + p.data_ofs, p, data);
+    return STK_OK;
+}
+
+stk_status stk_keypoint_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_keypoint_params* params,
+                                    float scale_down_width, stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats) {
+    return match_files(ctx, paths, n, [&](const stk_frames* fr) { return stk_keypoint_match(ctx, fr, params, scale_down_width, out, dropped, stats); });
+}
+
+stk_status stk_ecc_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_ecc_params* params,
+                               float scale_down_width, stk_image_f32* out, stk_frame_stats* stats) {
+    return match_files(ctx, paths, n, [&](const stk_frames* fr) { return stk_ecc_match(ctx, fr, params, scale_down_width, out, stats); });
+}
+
+}  // extern "C"

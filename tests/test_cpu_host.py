@@ -155,3 +155,20 @@ def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert run.returncode == 0, run.stdout + run.stderr
     assert run.stdout.startswith("libstacker_rs_amd")
+
+
+def test_imread_pnm_without_a_gpu(tmp_path):
+    """stk_imread is pure host code and accepts a NULL context: binary PNM round trip, RGB on disk -> BGR in memory."""
+    lib = _ffi.load()
+    img = np.random.default_rng(0).integers(0, 256, (7, 9, 3), dtype=np.uint8)
+    p = tmp_path / "x.ppm"
+    p.write_bytes(b"P6\n# c\n9 7\n255\n" + np.ascontiguousarray(img[..., ::-1]).tobytes())
+    w, h, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.stk_imread(None, os.fsencode(p), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+    assert (w.value, h.value, c.value, d.value) == (9, 7, 3, 8)
+    out = np.empty((7, 9, 3), np.uint8)
+    assert lib.stk_imread(None, os.fsencode(p), C.c_void_p(out.ctypes.data), out.nbytes, None, None, None, None) == 0
+    assert np.array_equal(out, img)
+    assert lib.stk_imread(None, os.fsencode(p), C.c_void_p(out.ctypes.data), 10, None, None, None, None) == 2      # INVALID_PARAMS
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "nope.ppm"), None, 0, None, None, None, None) == 4         # BACKEND_ERROR
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), None, 0, None, None, None, None) == 7            # NOT_IMPLEMENTED

@@ -1,0 +1,72 @@
+"""The file front-end: imread of binary PNM and the path-based entry points, against the frame-based ones."""
+import numpy as np
+import pytest
+
+from libstacker_rs_amd import (EccMatchParameters, KeyPointMatchParameters, MotionType, NotEnoughFiles, NotImplementedYet,
+                               OpenCvError, RANSAC, synth)
+
+pytestmark = pytest.mark.gpu
+
+
+def write_pnm(path, img):
+    """P6 (HxWx3 BGR in, RGB on disk) or P5 (HxW), 8 or 16 bit (big-endian), with a comment line in the header."""
+    a = np.asarray(img)
+    maxval = 255 if a.dtype == np.uint8 else 65535
+    if a.ndim == 3:
+        a = a[..., ::-1]
+        head = f"P6\n# written by the test\n{a.shape[1]} {a.shape[0]}\n{maxval}\n"
+    else:
+        head = f"P5\n{a.shape[1]} {a.shape[0]}\n{maxval}\n"
+    raster = np.ascontiguousarray(a).astype(">u2").tobytes() if maxval == 65535 else np.ascontiguousarray(a).tobytes()
+    with open(path, "wb") as f:
+        f.write(head.encode() + raster)
+
+
+def test_imread_pnm_variants(stacker, tmp_path):
+    rng = np.random.default_rng(0)
+    for name, img in (("c8.ppm", rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)),
+                      ("g8.pgm", rng.integers(0, 256, (20, 31), dtype=np.uint8)),
+                      ("c16.ppm", rng.integers(0, 65536, (11, 17, 3), dtype=np.uint16)),
+                      ("g16.pgm", rng.integers(0, 65536, (9, 5), dtype=np.uint16))):
+        p = tmp_path / name
+        write_pnm(p, img)
+        got = stacker.imread(p)
+        assert got.dtype == img.dtype and np.array_equal(got, img)
+    with pytest.raises(OpenCvError):
+        stacker.imread(tmp_path / "missing.ppm")                   # empty Mat -> cvtColor raises in the reference
+    (tmp_path / "junk.ppm").write_bytes(b"not an image at all")
+    with pytest.raises(OpenCvError):
+        stacker.imread(tmp_path / "junk.ppm")
+    (tmp_path / "short.ppm").write_bytes(b"P6\n4 4\n255\n\x00\x01")
+    with pytest.raises(OpenCvError):
+        stacker.imread(tmp_path / "short.ppm")
+    with pytest.raises(NotImplementedYet):
+        stacker.imread(tmp_path / "photo.jpg")                     # needs libjpeg: not in this build
+
+
+def test_path_based_entry_points_equal_frame_based(stacker, tmp_path):
+    frames, _ = synth.make_stack(4, 320, 240)
+    fr = frames.numpy()
+    paths = []
+    for i, f in enumerate(fr):
+        paths.append(tmp_path / f"frame_{i:02d}.ppm")
+        write_pnm(paths[-1], f)
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    ecc = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
+    d_f, out_f = stacker.keypoint_match_files(paths, kp)
+    d_a, out_a = stacker.keypoint_match(list(fr), kp)
+    assert d_f == d_a == 0 and np.array_equal(out_f, out_a)
+    assert np.array_equal(stacker.ecc_match_files(paths, ecc), stacker.ecc_match(list(fr), ecc))
+    with pytest.raises(NotEnoughFiles):
+        stacker.ecc_match_files([], ecc)
+    # a grey file in the list: cvtColor(BGR2GRAY) on a 1-channel Mat raises in the reference (utils.rs:136)
+    write_pnm(tmp_path / "grey.pgm", fr[0][..., 0])
+    with pytest.raises(OpenCvError):
+        stacker.ecc_match_files([tmp_path / "grey.pgm", tmp_path / "grey.pgm"], ecc)
+    # 16-bit colour files: ORB asserts 8-bit, findTransformECC rejects 16UC1
+    write_pnm(tmp_path / "a16.ppm", fr[0].astype(np.uint16) * 257)
+    write_pnm(tmp_path / "b16.ppm", fr[1].astype(np.uint16) * 257)
+    with pytest.raises(OpenCvError):
+        stacker.keypoint_match_files([tmp_path / "a16.ppm", tmp_path / "b16.ppm"], kp)
+    with pytest.raises(OpenCvError):
+        stacker.ecc_match_files([tmp_path / "a16.ppm", tmp_path / "b16.ppm"], ecc)
