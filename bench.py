@@ -35,6 +35,8 @@ WORKLOADS = {
     "ecc_1080p": (1920, 1080, 64, "ecc"),
     "keypoint_1080p": (1920, 1080, 64, "keypoint"),
     "ecc_small": (640, 480, 8, "ecc"),
+    # BASELINE configs[4] (an extension beyond the reference): 16-bit 4K stack, ORB-seeded ECC refine
+    "hybrid_4k16": (3840, 2160, 32, "hybrid"),
 }
 
 
@@ -94,7 +96,7 @@ def main() -> None:
 
     t0 = time.time()
     scene = synth.render_scene(W, H)
-    frames, G = synth.make_stack(0, W, H, scene=scene, device=dev, indices=[0] + mine)
+    frames, G = synth.make_stack(0, W, H, scene=scene, device=dev, indices=[0] + mine, depth=16 if api == "hybrid" else 8)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 
@@ -151,6 +153,9 @@ def main() -> None:
         step_no += 1
         if api == "ecc":
             added, stats = st.ecc_match_shard(frames, ecc_params, rank == 0, acc)
+            dropped = 0
+        elif api == "hybrid":
+            added, stats = st.hybrid_match_shard(frames, kp_params, ecc_params, rank == 0, acc)
             dropped = 0
         else:
             added, dropped, stats = st.keypoint_match_shard(frames, kp_params, rank == 0, acc)
@@ -212,8 +217,9 @@ def main() -> None:
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n_global}-frame {W}x{H} BGR u8 stack, "
-                                   + ("ecc_match Homography max_count 5000 eps 1e-5 gauss 5" if api == "ecc"
+            "config": {"workload": f"{args.workload}: {n_global}-frame {W}x{H} BGR {'u16' if api == 'hybrid' else 'u8'} stack, "
+                                   + ("ORB-seeded ecc_match (extension, 16-bit) Homography max_count 5000 eps 1e-5 gauss 5" if api == "hybrid" else
+                                      "ecc_match Homography max_count 5000 eps 1e-5 gauss 5" if api == "ecc"
                                       else "keypoint_match RANSAC thr 5.0 ratio 0.9 keep 0.80")
                                    + f", {fpg} frames/GPU resident in HBM, frame-sharded, one accumulator reduce",
                        "frames_per_gpu": fpg, "width": W, "height": H, "parallelism": f"frame-shard x{world}",
@@ -222,7 +228,7 @@ def main() -> None:
                                               if overlap else "RCCL reduce to rank 0, waited for before the next step")},
         }
         # ---- roofline of the dominant kernel --------------------------------------------------
-        if api == "ecc" and agg["ecc_iter_timed"] > 0:
+        if api in ("ecc", "hybrid") and agg["ecc_iter_timed"] > 0:
             # ECC iteration kernel: ALGORITHMIC bytes = 16 B/px per frame-iteration (template 4 B +
             # frame-0 image/gx/gy 12 B); one launch advances `slots` frames by one iteration.
             alg_bytes_total = 16.0 * px * agg["ecc_slot_iterations"]
@@ -271,6 +277,10 @@ def main() -> None:
             tc = time.perf_counter()
             if api == "ecc":
                 oracle.ecc_match(sample, max_count=5000, epsilon=1e-5, gauss_filt_size=5, n_threads=use)
+            elif api == "hybrid":
+                use, sample = 1, sample[:3]                     # the oracle's hybrid path is a serial Python composition
+                n_s = len(sample)
+                oracle.hybrid_match(sample)
             else:
                 oracle.keypoint_match(sample, n_threads=use)
             cpu_s = time.perf_counter() - tc

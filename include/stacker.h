@@ -184,6 +184,17 @@ stk_status stk_grey(stk_ctx* ctx, const stk_frames* frame /* n==1 */, void* out)
 /* Mat::convert_to(CV_32F, alpha) utils.rs:133 (alpha = 1/255 there). */
 stk_status stk_convert_f32(stk_ctx* ctx, const stk_frames* frame /* n==1 */, double alpha,
                            float* out);
+/* ---- BASELINE configs[4]: ORB-seeded ECC on 8- or 16-bit stacks — an EXTENSION beyond the reference --------------
+ * (both reference paths reject 16-bit input). Definition: ORB + RANSAC homography on the 8-bit grey
+ * ((grey16 + 128) / 257 for 16-bit frames), H / h22 cast to f32 is the initial warp of findTransformECC (Homography)
+ * on float(grey), fold with alpha = 1/65535 (16-bit) or 1/255 (8-bit). A frame without a homography starts from the
+ * identity; nothing is dropped. stats carry the ECC result plus the keypoint / match / inlier counts. */
+stk_status stk_hybrid_match(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* kp_params,
+                            const stk_ecc_params* ecc_params, stk_image_f32* out, stk_frame_stats* stats);
+stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* kp_params,
+                                  const stk_ecc_params* ecc_params, int32_t add_reference, stk_image_f32* sum,
+                                  int32_t* n_added, stk_frame_stats* stats);
+
 /* ---- file front-end ---------------------------------------------------------
  * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit): BGR or grey
  * rows, tightly packed, into `data` (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.

@@ -71,6 +71,10 @@ SIGNATURES = {
     "stk_finalize_mean": (c_status, [C.c_void_p, C.POINTER(ImageF32), C.c_int64, C.POINTER(ImageF32)]),
     "stk_grey": (c_status, [C.c_void_p, C.POINTER(Frames), C.c_void_p]),
     "stk_convert_f32": (c_status, [C.c_void_p, C.POINTER(Frames), C.c_double, C.c_void_p]),
+    "stk_hybrid_match": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(KeypointParams), C.POINTER(EccParams),
+                                    C.POINTER(ImageF32), C.POINTER(FrameStats)]),
+    "stk_hybrid_match_shard": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(KeypointParams), C.POINTER(EccParams), C.c_int32,
+                                          C.POINTER(ImageF32), C.POINTER(C.c_int32), C.POINTER(FrameStats)]),
     "stk_imread": (c_status, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stk_keypoint_match_files": (c_status, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(KeypointParams), C.c_float,

@@ -336,6 +336,31 @@ class Stacker:
         self._check(self._lib.stk_convert_f32(self._h, C.byref(m.c_frames), float(alpha), C.c_void_p(ptr)))
         return out
 
+    # -- BASELINE configs[4] (extension): ORB-seeded ECC on 8- or 16-bit stacks --------------------------------
+    def hybrid_match(self, files, kp_params: KeyPointMatchParameters, ecc_params: EccMatchParameters, return_stats=False):
+        """ORB + RANSAC homography as the initial warp of findTransformECC; 16-bit frames folded with alpha 1/65535."""
+        m = _Marshalled(files)
+        if m.n == 0:
+            raise NotEnoughFiles("Not enough files")
+        out, img = self._out_image(m)
+        stats = (_ffi.FrameStats * m.n)()
+        kp, ep = kp_params._c(), ecc_params._c()
+        self._check(self._lib.stk_hybrid_match(self._h, C.byref(m.c_frames), C.byref(kp), C.byref(ep), C.byref(img), stats))
+        return (out, self._stats_list(stats, m.n)) if return_stats else out
+
+    def hybrid_match_shard(self, files, kp_params: KeyPointMatchParameters, ecc_params: EccMatchParameters,
+                           add_reference: bool, sum_out):
+        m = _Marshalled(files)
+        if m.n == 0:
+            raise NotEnoughFiles("Not enough files")
+        img = _ffi.ImageF32(sum_out.data_ptr(), m.w, m.h, 3, DEVICE, 0)
+        added = C.c_int32(0)
+        stats = (_ffi.FrameStats * m.n)()
+        kp, ep = kp_params._c(), ecc_params._c()
+        self._check(self._lib.stk_hybrid_match_shard(self._h, C.byref(m.c_frames), C.byref(kp), C.byref(ep),
+                                                     int(bool(add_reference)), C.byref(img), C.byref(added), stats))
+        return added.value, self._stats_list(stats, m.n)
+
     # -- file front-end (SURVEY 8f-3): the reference's entry points take paths ------------------------------
     def imread(self, path):
         """imgcodecs::imread(path, IMREAD_UNCHANGED) for binary PNM (P5 / P6, 8 or 16 bit): HxW or HxWx3 (BGR) array."""

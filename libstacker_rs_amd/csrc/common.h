@@ -116,6 +116,7 @@ hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_b
                        int n_frames = 1, size_t src_frame_bytes = 0, size_t out_frame_elems = 0);
 hipError_t launch_convert_f32(const void* src, int depth, size_t n, float alpha, float* out, hipStream_t s);
 // BGR (cn==3) or grey (cn==1) image -> GaussianBlur(float(grey), ksize) f32 plane with row stride out_stride
+hipError_t launch_grey16_to_8(const uint16_t* src, size_t n, uint8_t* dst, hipStream_t s);
 hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, size_t stride_bytes, int ksize,
                             float* out, int out_stride, hipStream_t s);
 // blurred plane (stride in_stride) -> padded I/gx/gy planes
@@ -125,7 +126,7 @@ hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, 
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s);
 constexpr int ECC_TILE_W = 64, ECC_TILE_H = 16;
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
-                            EccFrameResult* results, hipStream_t s);
+                            EccFrameResult* results, hipStream_t s, const float* init_warps = nullptr);
 hipError_t launch_sharpness(const void* grey, int depth, int w, int h, int metric, int ksize, void* partials, int n_blocks,
                             hipStream_t s);
 hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,

@@ -75,3 +75,13 @@ stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int 
 size_t image_stride_floats(const stk_image_f32* im);
 void timing_begin(stk_ctx* ctx);
 float ev_ms(hipEvent_t a, hipEvent_t b);
+
+// shared internals of the entry points (stacker.cpp / keypoint.cpp / hybrid.cpp)
+stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params, float scale_down_width,
+                          int32_t add_reference, stk_image_f32* sum, int32_t* n_added, stk_frame_stats* stats,
+                          const float* seeds, double alpha, bool allow16);
+struct KpAlign { bool ok = false; double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; int n_keypoints = 0, n_matches = 0, n_inliers = 0; };
+// keypoint_match's alignment half: ORB + 2-NN + ratio / sort / truncate + homography per moving frame (no fold).
+// reduce16: 16-bit frames are matched on their 8-bit reduction (g + 128) / 257 (hybrid extension only).
+stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params, float scale_down_width,
+                               bool reduce16, std::vector<KpAlign>& out, int* n_ref_keypoints, std::vector<const void*>& dev);

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motio
 }
 
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
-                            EccFrameResult* results, hipStream_t s) {
-    ecc_solve_kernel<<<a.n_slots * SOLVE_G, 256, 0, s>>>(a, motion, crit, queue, results, nullptr);
+                            EccFrameResult* results, hipStream_t s, const float* init_warps) {
+    ecc_solve_kernel<<<a.n_slots * SOLVE_G, 256, 0, s>>>(a, motion, crit, queue, results, init_warps);
     return hipGetLastError();
 }
 

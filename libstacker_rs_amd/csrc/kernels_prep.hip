@@ -73,6 +73,19 @@ hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_b
     return hipGetLastError();
 }
 
+// 16-bit grey -> 8-bit grey for ORB on 16-bit stacks (BASELINE configs[4], an extension: SURVEY 8d): (g + 128) / 257
+__global__ __launch_bounds__(256) void grey16_to_8_kernel(const uint16_t* __restrict__ src, size_t n, uint8_t* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i < n; i += step) dst[i] = (uint8_t)(((unsigned)src[i] + 128u) / 257u);
+}
+
+hipError_t launch_grey16_to_8(const uint16_t* src, size_t n, uint8_t* dst, hipStream_t s) {
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 8192));
+    grey16_to_8_kernel<<<blocks, 256, 0, s>>>(src, n, dst);
+    return hipGetLastError();
+}
+
 // ---- convert ----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void convert_kernel(const T* __restrict__ src, size_t n, float alpha,
@@ -129,6 +142,7 @@ __global__ __launch_bounds__(256) void grey_blur_kernel(const T* __restrict__ sr
         float v;
         if constexpr (CN == 1) v = (float)p[0];
         else if constexpr (sizeof(T) == 1) v = (float)grey_u8(p[0], p[1], p[2]);
+        else if constexpr (sizeof(T) == 2) v = (float)grey_u16(p[0], p[1], p[2]);
         else v = grey_f32((float)p[0], (float)p[1], (float)p[2]);
         G[i] = v;
     }
@@ -268,6 +282,8 @@ hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, si
     dim3 grid((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y);
     if (depth == 8 && cn == 3) grey_blur_kernel<uint8_t, 3><<<grid, 256, lds_bytes, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
     else if (depth == 8 && cn == 1) grey_blur_kernel<uint8_t, 1><<<grid, 256, lds_bytes, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+    else if (depth == 16 && cn == 3) grey_blur_kernel<uint16_t, 3><<<grid, 256, lds_bytes, s>>>((const uint16_t*)src, stride_bytes / 2, w, h, taps, out, out_stride);
+    else if (depth == 16 && cn == 1) grey_blur_kernel<uint16_t, 1><<<grid, 256, lds_bytes, s>>>((const uint16_t*)src, stride_bytes / 2, w, h, taps, out, out_stride);
     else if (depth == 32 && cn == 3) grey_blur_kernel<float, 3><<<grid, 256, lds_bytes, s>>>((const float*)src, stride_bytes / 4, w, h, taps, out, out_stride);
     else if (depth == 32 && cn == 1) grey_blur_kernel<float, 1><<<grid, 256, lds_bytes, s>>>((const float*)src, stride_bytes / 4, w, h, taps, out, out_stride);
     else return hipErrorInvalidValue;

@@ -420,15 +420,17 @@ stk_status stk_find_homography(stk_ctx* ctx, const float* src_pts, const float* 
     return STK_OK;
 }
 
-stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params,
-                                    float scale_down_width, int32_t add_reference, stk_image_f32* sum,
-                                    int32_t* n_added, int32_t* n_dropped, stk_frame_stats* stats) {
+}  // extern "C"
+
+stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params, float scale_down_width,
+                               bool reduce16, std::vector<KpAlign>& out, int* n_ref_keypoints, std::vector<const void*>& dev) {
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
     if (!params) return fail(ctx, STK_INVALID_PARAMS, "null params");
     (void)hipSetDevice(ctx->device);
-    if (frames->depth != 8)   // ORB::detectAndCompute asserts an 8-bit image
+    if (frames->depth != 8 && !(reduce16 && frames->depth == 16))   // ORB::detectAndCompute asserts an 8-bit image
         return fail(ctx, STK_BACKEND_ERROR, "ORB: only 8-bit images are supported");
+    if (reduce16 && frames->depth == 16 && scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "scale_down_width with 16-bit frames");
     if (params->method != STK_METHOD_RANSAC && params->method != STK_METHOD_LEAST_SQUARES && params->method != STK_METHOD_LMEDS) {
         if (params->method == STK_METHOD_RHO)
             return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: RHO is not implemented");
@@ -447,12 +449,8 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
                                                   std::to_string(w) + ", scale_down_to:" + std::to_string(scale_down_width));
         if (!scaled_size(w, h, scale_down_width, ew, eh)) return fail(ctx, STK_INVALID_PARAMS, "scale_down_width gives an empty image");
     }
-    if ((st = image_check(ctx, sum, w, h, 3))) return st;
-    if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
-    timing_begin(ctx);
 
-    std::vector<const void*> dev;
-    if ((st = resolve_frames(ctx, frames, dev))) return st;
+    if ((st = resolve_frames(ctx, frames, dev))) return st;      // device pointers of the frames, returned to the caller
     const size_t rb = frame_row_bytes(frames);
     OrbGeometry g;
     orb_geometry(ew, eh, g);
@@ -462,7 +460,8 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     KeypointWorkspace* ws = ctx->kp;
     hipStream_t s = ctx->stream;
     const int threads = ctx->opt_kp_workers;
-    if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
+    const bool depth16 = frames->depth == 16;
+    if (scaled || depth16) HIP_TRY(ws->gfull.reserve((size_t)w * h * (depth16 ? 2 : 1)));
     HIP_TRY(ws->desc0.reserve(MAX_KP * 32));
     HIP_TRY(ws->desc.reserve(MAX_KP * 32 * (size_t)batch));
     HIP_TRY(ws->knn.reserve(MAX_KP * 16 * (size_t)batch));
@@ -476,17 +475,20 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     // grey of a frame into level 0 of pyramid `slot`, through scale_image when scaling (utils.rs:186-214)
     auto grey_level0 = [&](const void* frame, int slot) -> stk_status {
         uint8_t* l0 = ws->pyr.as<uint8_t>() + (size_t)slot * g.pyr.total;
+        if (depth16) {                                         // grey16 (16U formula) -> (g + 128) / 257
+            HIP_TRY(launch_grey(frame, 16, w, h, rb, ws->gfull.p, s));
+            HIP_TRY(launch_grey16_to_8(ws->gfull.as<uint16_t>(), (size_t)w * h, l0, s));
+            return STK_OK;
+        }
         if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, l0, s)); return STK_OK; }
         HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->gfull.p, s));
         HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, l0, ew, eh, s));
         return STK_OK;
     };
     const double fix_sx = (double)w / (double)ew, fix_sy = (double)h / (double)eh;   // adjust_homography_for_scale_f64
-    if (stats) std::memset(stats, 0, sizeof(stk_frame_stats) * n);
 
-    HIP_TRY(hipEventRecord(ctx->ev[0], s));
-    struct FrameResult { bool ok = false; double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; int nk = 0, n_matches = 0, n_inl = 0; };
-    std::vector<FrameResult> results(n);
+    std::vector<KpAlign>& results = out;
+    results.assign(n, KpAlign{});
     std::vector<HostKeypoint> kp0;
     int n0 = 0;
     // Batches of frames go through ORB together (one launch per stage and level for the whole batch); the first batch
@@ -495,7 +497,7 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     for (int b0 = 0; b0 < n; b0 += batch) {
         const int nb = std::min(batch, n - b0);
         // level 0 of every pyramid of the batch: one launch when the frames are evenly spaced in memory (a tensor), else per frame
-        bool even = !scaled && nb > 1;
+        bool even = !scaled && !depth16 && nb > 1;
         const ptrdiff_t fstep = nb > 1 ? (const uint8_t*)dev[b0 + 1] - (const uint8_t*)dev[b0] : 0;
         for (int k = 1; even && k + 1 < nb; k++) even = ((const uint8_t*)dev[b0 + k + 1] - (const uint8_t*)dev[b0 + k]) == fstep;
         if (even && fstep > 0) HIP_TRY(launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total));
@@ -509,7 +511,6 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
             kp0 = kps[0];
             n0 = (int)kp0.size();
             if (n0 > 0) HIP_TRY(hipMemcpyAsync(ws->desc0.p, ws->desc.p, (size_t)n0 * 32, hipMemcpyDeviceToDevice, s));
-            if (stats) { stats[0].n_keypoints = n0; stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1; }
             first = 1;
         }
         const int n_mov = nb - first;
@@ -528,8 +529,8 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
         parallel_for(ctx, n_mov, threads, [&](int m) {
             const int i = b0 + first + m;
             const std::vector<HostKeypoint>& kp = kps[first + m];
-            FrameResult& R = results[i];
-            R.nk = (int)kp.size();
+            KpAlign& R = results[i];
+            R.n_keypoints = (int)kp.size();
             bool ok = true;
             double* H = R.H;
             std::vector<Match> ms;
@@ -560,11 +561,38 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
                     const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
                     if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284 / 521 (on the small-image H)
                     else if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
-                    for (uint8_t mk : mask) R.n_inl += mk;
+                    for (uint8_t mk : mask) R.n_inliers += mk;
                 }
             }
             R.ok = ok; R.n_matches = (int)ms.size();
         });
+    }
+
+    if (n_ref_keypoints) *n_ref_keypoints = n0;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+extern "C" {
+
+stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params,
+                                    float scale_down_width, int32_t add_reference, stk_image_f32* sum,
+                                    int32_t* n_added, int32_t* n_dropped, stk_frame_stats* stats) {
+    stk_status st = check_frames(ctx, frames, true);
+    if (st) return st;
+    const int w = frames->width, h = frames->height, n = frames->n;
+    if ((st = image_check(ctx, sum, w, h, 3))) return st;
+    if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
+    timing_begin(ctx);
+    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    std::vector<KpAlign> results;
+    int n0 = 0;
+    std::vector<const void*> dev;
+    if ((st = keypoint_align_impl(ctx, frames, params, scale_down_width, false, results, &n0, dev))) return st;
+    const size_t rb = frame_row_bytes(frames);
+    if (stats) {
+        std::memset(stats, 0, sizeof(stk_frame_stats) * n);
+        stats[0].n_keypoints = n0; stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1;
     }
 
     // fold order = frame order: the f32 sum is reproducible
@@ -574,9 +602,9 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     if (add_reference) { wf.emplace_back(); make_warp_frame(wf.back(), dev[0], I3, 0); }
     int dropped = 0;
     for (int i = 1; i < n; i++) {
-        const FrameResult& R = results[i];
+        const KpAlign& R = results[i];
         if (stats) {
-            stats[i].status = R.ok ? 0 : 1; stats[i].n_keypoints = R.nk; stats[i].n_matches = R.n_matches; stats[i].n_inliers = R.n_inl;
+            stats[i].status = R.ok ? 0 : 1; stats[i].n_keypoints = R.n_keypoints; stats[i].n_matches = R.n_matches; stats[i].n_inliers = R.n_inliers;
             for (int k = 0; k < 9; k++) stats[i].warp[k] = R.H[k];
         }
         if (!R.ok) { dropped++; continue; }

@@ -263,7 +263,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                     if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used], ctx->stream));
                     HIP_TRY(launch_ecc_iter(a, pl.motion, ctx->opt_ecc_variant, ctx->stream));
                     if (timed) { HIP_TRY(hipEventRecord(ctx->prof_ev[prof_used + 1], ctx->stream)); prof_used += 2; }
-                    HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream));
+                    HIP_TRY(launch_ecc_solve(a, pl.motion, crit, q, r, ctx->stream, init_warps_dev));
                 }
                 launched += chunk;
                 ctx->timing.ecc_iter_launches += chunk;
@@ -349,17 +349,18 @@ size_t image_stride_floats(const stk_image_f32* im) {
 
 void timing_begin(stk_ctx* ctx) { std::memset(&ctx->timing, 0, sizeof(ctx->timing)); }
 
-extern "C" {
-
-stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params,
-                               float scale_down_width, int32_t add_reference, stk_image_f32* sum,
-                               int32_t* n_added, stk_frame_stats* stats) {
+// ecc_match on a shard. `seeds` (n x 9 f32, row-major, h22 == 1; entry 0 unused) replaces the identity as the initial
+// warp of every moving frame; `alpha` is the convertTo scale of the fold; `allow16` admits 16-bit frames (ECC then runs on
+// float(grey16)) — both only for the hybrid extension (stk_hybrid_match): the reference's ecc_match is (nullptr, 1/255, false).
+stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params, float scale_down_width,
+                          int32_t add_reference, stk_image_f32* sum, int32_t* n_added, stk_frame_stats* stats,
+                          const float* seeds, double alpha, bool allow16) {
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
     (void)hipSetDevice(ctx->device);
     EccCriteria crit{};
     if ((st = ecc_validate(ctx, params, crit))) return st;
-    if (frames->depth == 16)  // findTransformECC accepts CV_8UC1 / CV_32FC1 only
+    if (frames->depth == 16 && !allow16)  // findTransformECC accepts CV_8UC1 / CV_32FC1 only
         return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: 16-bit images are not supported (8UC1 or 32FC1 only)");
     const int w = frames->width, h = frames->height, n = frames->n;
     // ecc_match_scaling_down (lib.rs:849-1028): ECC on INTER_AREA-shrunk greys, then the warp is rescaled
@@ -404,8 +405,14 @@ stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk
         }
     }
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    const float* seeds_dev = nullptr;
+    if (seeds && n > 1) {
+        HIP_TRY(ctx->init_warps.reserve(sizeof(float) * 9 * (size_t)(n - 1)));
+        HIP_TRY(hipMemcpyAsync(ctx->init_warps.p, seeds + 9, sizeof(float) * 9 * (size_t)(n - 1), hipMemcpyHostToDevice, ctx->stream));
+        seeds_dev = ctx->init_warps.as<float>();
+    }
     std::vector<EccFrameResult> res;
-    if ((st = ecc_run(ctx, pl, crit, nullptr, res))) return st;
+    if ((st = ecc_run(ctx, pl, crit, seeds_dev, res))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
 
     const int is_affine = params->motion_type != STK_MOTION_HOMOGRAPHY;
@@ -448,7 +455,7 @@ stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk
         make_warp_frame(wf.back(), dev[i], M, is_affine);
     }
     if (wf.empty()) HIP_TRY(hipMemsetAsync(sum->data, 0, image_stride_floats(sum) * h * sizeof(float), ctx->stream));
-    if ((st = warp_fold(ctx, wf, frames->depth, w, h, 3, rb, 1.0 / 255.0, STK_BORDER_CONSTANT, nullptr, is_affine,
+    if ((st = warp_fold(ctx, wf, frames->depth, w, h, 3, rb, alpha, STK_BORDER_CONSTANT, nullptr, is_affine,
                         sum->data, image_stride_floats(sum), 0))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -457,6 +464,14 @@ stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk
     ctx->timing.warp_ms = ev_ms(ctx->ev[2], ctx->ev[3]);
     if (n_added) *n_added = (int32_t)wf.size();
     return STK_OK;
+}
+
+extern "C" {
+
+stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params,
+                               float scale_down_width, int32_t add_reference, stk_image_f32* sum,
+                               int32_t* n_added, stk_frame_stats* stats) {
+    return ecc_shard_impl(ctx, frames, params, scale_down_width, add_reference, sum, n_added, stats, nullptr, 1.0 / 255.0, false);
 }
 
 stk_status stk_finalize_mean(stk_ctx* ctx, const stk_image_f32* sum, int64_t n_frames, stk_image_f32* out) {

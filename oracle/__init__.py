@@ -260,3 +260,49 @@ def sharpness(grey, metric: int, ksize: int = 0) -> float:
     if rc:
         raise ValueError("orc_sharpness rc=%d" % rc)
     return out.value
+
+
+def hybrid_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0, match_keep_ratio: float = 0.80,
+                 match_ratio: float = 0.9, max_count=5000, epsilon=1e-5, gauss_filt_size=5):
+    """BASELINE configs[4] (an extension beyond the reference), composed from the oracle's stages: ORB + RANSAC
+    homography on the 8-bit grey ((grey16 + 128) / 257 for 16-bit frames) seeds findTransformECC (Homography) on float(grey);
+    fold with alpha = 1/65535 (16-bit) or 1/255. Returns (image, warps [n,3,3] f32, iterations, seeds [n,3,3] f32)."""
+    import math
+    frames = [np.ascontiguousarray(f) for f in frames]
+    n = len(frames)
+    is16 = frames[0].dtype == np.uint16
+    greys = [grey(f) for f in frames]
+    g8 = [((g.astype(np.uint32) + 128) // 257).astype(np.uint8) if is16 else g for g in greys]
+    gf = [g.astype(np.float32) if is16 else g for g in greys]          # ECC input: float(grey16) / the 8-bit grey
+    kp0, de0 = orb_detect_and_compute(g8[0])
+    warps = np.zeros((n, 3, 3), np.float32); warps[0] = np.eye(3)
+    seeds = np.zeros((n, 3, 3), np.float32); seeds[:] = np.eye(3)
+    iters = np.zeros(n, np.int32)
+    alpha = 1.0 / 65535.0 if is16 else 1.0 / 255.0
+    acc = warp_frame(frames[0], np.eye(3), alpha=alpha)
+    for i in range(1, n):
+        kp, de = orb_detect_and_compute(g8[i])
+        ms = []
+        if len(kp0):
+            knn = bf_knn2_hamming(de0, de)
+            for q in range(len(kp0)):
+                if knn[q, 0] < 0 or knn[q, 2] < 0:
+                    continue
+                if np.float32(knn[q, 1]) < np.float32(match_ratio) * np.float32(knn[q, 3]):    # lib.rs:224
+                    ms.append((q, int(knn[q, 0]), float(knn[q, 1])))
+            ms.sort(key=lambda m: m[2])                                                         # stable, lib.rs:233
+            keep = int(math.floor(float(np.float32(len(ms)) * np.float32(match_keep_ratio)) + 0.5))   # round(), lib.rs:235
+            ms = ms[:keep] if keep < len(ms) else ms
+        if len(ms) >= 5:                                                                        # lib.rs:240
+            src0 = np.array([[kp0[q][0], kp0[q][1]] for q, _, _ in ms], np.float32)
+            dsti = np.array([[kp[t][0], kp[t][1]] for _, t, _ in ms], np.float32)
+            H, _ = find_homography(dsti, src0, method, ransac_reproj_threshold)                 # frame i -> frame 0, lib.rs:267
+            if H is not None and abs(np.linalg.det(H)) >= 1e-6 and abs(H[2, 2]) > 1e-12:
+                seeds[i] = (H / H[2, 2]).astype(np.float32)
+                seeds[i][2, 2] = 1.0
+        rc, W, rho, its = find_transform_ecc(gf[i], gf[0], seeds[i], MOTION_HOMOGRAPHY, max_count, epsilon, gauss_filt_size)
+        if rc:
+            raise RuntimeError("hybrid_match: findTransformECC rc=%d on frame %d" % (rc, i))
+        warps[i], iters[i] = W, its
+        acc = warp_frame(frames[i], W.astype(np.float64), alpha=alpha, acc=acc)
+    return scale(acc, n), warps, iters, seeds

@@ -1,0 +1,58 @@
+"""BASELINE configs[4] — ORB-seeded ECC on 8- and 16-bit stacks (an extension beyond the reference) vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from libstacker_rs_amd import (EccMatchParameters, InvalidParams, KeyPointMatchParameters, MotionType, OpenCvError, RANSAC,
+                               synth)
+
+pytestmark = pytest.mark.gpu
+
+KP = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+ECC = EccMatchParameters(MotionType.Homography, 200, 1e-5, 5)      # bounded: see the note on iteration counts below
+
+
+def _stack16(n, w, h):
+    frames, G = synth.make_stack(n, w, h)
+    f8 = frames.numpy()
+    rng = np.random.default_rng(11)
+    f16 = f8.astype(np.uint16) * 257 + rng.integers(0, 200, f8.shape, dtype=np.uint16)      # real 16-bit content, not just scaled 8-bit
+    return np.minimum(f16, 65535).astype(np.uint16), f8, G
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+def test_hybrid_match_matches_oracle(stacker, bits):
+    f16, f8, G = _stack16(4, 640, 480)
+    fr = f16 if bits == 16 else f8
+    out, stats = stacker.hybrid_match(list(fr), KP, ECC, return_stats=True)
+    ref, warps, iters, seeds = oracle.hybrid_match(list(fr), max_count=200)
+    for i in range(1, len(fr)):
+        assert stats[i]["n_matches"] >= 50                                        # the ORB seed exists ...
+        assert synth.corner_error(seeds[i], G[i], 640, 480) <= 1.5               # ... and is already close
+        assert synth.corner_error(stats[i]["warp"], warps[i], 640, 480) <= 0.05   # ECC result vs oracle
+        # Started this close to the optimum, |rho - last_rho| hovers around eps from the first iterations on and the f32
+        # summation order decides which side it falls: the iteration COUNT is not comparable (one side may stop at 5, the
+        # other run to max_count while moving the corners by < 0.05 px); the warps are.
+        assert stats[i]["iterations"] <= 200 and int(iters[i]) <= 200
+        assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 0.3        # vs generator ground truth
+    rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert np.percentile(rel[4:-4, 4:-4], 99.5) < 3e-3
+    assert 0.0 <= out.min() and out.max() <= 1.0 + 1e-6                           # alpha 1/65535 resp. 1/255: unit range
+
+
+def test_hybrid_seed_shortens_ecc(stacker):
+    f16, f8, _ = _stack16(3, 640, 480)
+    _, cold = stacker.ecc_match(list(f8), ECC, return_stats=True)
+    _, warm = stacker.hybrid_match(list(f8), KP, ECC, return_stats=True)
+    assert sum(s["iterations"] for s in warm[1:]) < sum(s["iterations"] for s in cold[1:])
+
+
+def test_hybrid_falls_back_to_identity_and_rejects_bad_input(stacker):
+    f16, f8, _ = _stack16(3, 320, 240)
+    flat_ref = [np.full_like(f8[0], 90), f8[1], f8[2]]      # featureless reference: no descriptors, ECC from the identity
+    with pytest.raises(OpenCvError):                        # ... which cannot correlate with a constant image
+        stacker.hybrid_match(flat_ref, KP, ECC)
+    with pytest.raises(InvalidParams):
+        stacker.hybrid_match(list(f8), KP, EccMatchParameters(MotionType.Affine, 50, 1e-5, 5))
+    with pytest.raises(InvalidParams):
+        stacker.hybrid_match([f.astype(np.float32) for f in f8], KP, ECC)
