@@ -242,12 +242,113 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
     accp[0] = s0; accp[1] = s1; accp[2] = s2;
 }
 
+// 16-bit BGR fast path (16-bit stacks: stk_hybrid_match): the two horizontally adjacent taps of a row are 12 contiguous
+// bytes -> one 12-byte load; waves whose footprints are all interior take it, border waves take per-tap conditional loads.
+// Same operation sequence as the generic kernel.
+struct Tap12 { uint32_t a, b, c; };   // B0 G0 | R0 B1 | G1 R1 (16 bits each)
+
+__device__ __forceinline__ Tap12 load_tap12(const uint8_t* p) {
+    Tap12 t;
+    __builtin_memcpy(&t, p, 12);
+    return t;
+}
+
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.dw || y >= a.dh) return;
+    float* accp = a.acc + (size_t)y * a.acc_stride + (size_t)x * 3;
+    float s[3] = {0.f, 0.f, 0.f};
+    if (a.accumulate) { s[0] = accp[0]; s[1] = accp[1]; s[2] = accp[2]; }
+    const float fx = (float)x, fy = (float)y;
+    const int sw = a.sw, sh = a.sh;
+    const int stride_el = (int)a.src_stride;               // row stride in 16-bit elements
+    const float alpha = a.alpha;
+    const float bv[3] = {a.bv[0], a.bv[1], a.bv[2]};
+
+    for (int f0 = 0; f0 < a.n_frames; f0 += WU) {
+        float ax[WU], ay[WU];
+        int ix[WU], iy[WU];
+        bool interior = true;
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const WarpFrame* fr = a.frames + min(f0 + u, a.n_frames - 1);
+            float X = __builtin_fmaf(fr->M[0], fx, __builtin_fmaf(fr->M[1], fy, fr->M[2]));
+            float Y = __builtin_fmaf(fr->M[3], fx, __builtin_fmaf(fr->M[4], fy, fr->M[5]));
+            if (!AFFINE) {
+                const float W = __builtin_fmaf(fr->M[6], fx, __builtin_fmaf(fr->M[7], fy, fr->M[8]));
+                X = X / W; Y = Y / W;
+            }
+            const bool finite = (__builtin_fabsf(X) < 1e9f) & (__builtin_fabsf(Y) < 1e9f);
+            const float flx = __builtin_floorf(X), fly = __builtin_floorf(Y);
+            ix[u] = finite ? (int)flx : -100000; iy[u] = finite ? (int)fly : -100000;
+            ax[u] = finite ? X - flx : 0.0f; ay[u] = finite ? Y - fly : 0.0f;
+            interior &= ((unsigned)ix[u] < (unsigned)(sw - 1)) & ((unsigned)iy[u] < (unsigned)(sh - 1));
+        }
+#define STK_LERP16(p00, p01, p10, p11)                                                   \
+    __builtin_fmaf(ay[u], __builtin_fmaf(ax[u], (p11) - (p10), (p10)) - __builtin_fmaf(ax[u], (p01) - (p00), (p00)), \
+                   __builtin_fmaf(ax[u], (p01) - (p00), (p00)))
+        if (__all(interior)) {
+            Tap12 r0[WU], r1[WU];
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                const uint8_t* src = (const uint8_t*)a.frames[min(f0 + u, a.n_frames - 1)].src;
+                const unsigned o = (unsigned)(iy[u] * stride_el + ix[u] * 3) * 2u;
+                r0[u] = load_tap12(src + o);
+                r1[u] = load_tap12(src + o + (unsigned)stride_el * 2u);
+            }
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                if (f0 + u < a.n_frames) {
+                    const float t00[3] = {(float)(r0[u].a & 0xffffu) * alpha, (float)(r0[u].a >> 16) * alpha, (float)(r0[u].b & 0xffffu) * alpha};
+                    const float t01[3] = {(float)(r0[u].b >> 16) * alpha, (float)(r0[u].c & 0xffffu) * alpha, (float)(r0[u].c >> 16) * alpha};
+                    const float t10[3] = {(float)(r1[u].a & 0xffffu) * alpha, (float)(r1[u].a >> 16) * alpha, (float)(r1[u].b & 0xffffu) * alpha};
+                    const float t11[3] = {(float)(r1[u].b >> 16) * alpha, (float)(r1[u].c & 0xffffu) * alpha, (float)(r1[u].c >> 16) * alpha};
+#pragma unroll
+                    for (int c = 0; c < 3; c++) s[c] = s[c] + STK_LERP16(t00[c], t01[c], t10[c], t11[c]);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            if (f0 + u < a.n_frames) {
+                const uint16_t* src = (const uint16_t*)a.frames[f0 + u].src;
+                const int x0 = ix[u], y0 = iy[u];
+                const bool vx0 = (unsigned)x0 < (unsigned)sw, vx1 = (unsigned)(x0 + 1) < (unsigned)sw;
+                const bool vy0 = (unsigned)y0 < (unsigned)sh, vy1 = (unsigned)(y0 + 1) < (unsigned)sh;
+                const int xc0 = min(max(x0, 0), sw - 1), xc1 = min(max(x0 + 1, 0), sw - 1);
+                const int yc0 = min(max(y0, 0), sh - 1), yc1 = min(max(y0 + 1, 0), sh - 1);
+                const uint16_t* q0 = src + (size_t)yc0 * stride_el;
+                const uint16_t* q1 = src + (size_t)yc1 * stride_el;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float p00 = (vx0 & vy0) ? (float)q0[xc0 * 3 + c] * alpha : bv[c];
+                    const float p01 = (vx1 & vy0) ? (float)q0[xc1 * 3 + c] * alpha : bv[c];
+                    const float p10 = (vx0 & vy1) ? (float)q1[xc0 * 3 + c] * alpha : bv[c];
+                    const float p11 = (vx1 & vy1) ? (float)q1[xc1 * 3 + c] * alpha : bv[c];
+                    s[c] = s[c] + STK_LERP16(p00, p01, p10, p11);
+                }
+            }
+        }
+#undef STK_LERP16
+    }
+    accp[0] = s[0]; accp[1] = s[1]; accp[2] = s[2];
+}
+
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
     dim3 grid((a.dw + 63) / 64, (a.dh + 3) / 4);
     if (depth == 8 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 &&
         (size_t)a.sw * a.sh * 3 >= 16 && a.src_stride * (size_t)a.sh < ((size_t)1 << 31)) {
         if (a.is_affine) warp_accumulate_u8c3_kernel<true><<<grid, 256, 0, s>>>(a);
         else warp_accumulate_u8c3_kernel<false><<<grid, 256, 0, s>>>(a);
+        return hipGetLastError();
+    }
+    if (depth == 16 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 && a.sh >= 2 &&
+        a.src_stride * 2 * (size_t)a.sh < ((size_t)1 << 31)) {
+        if (a.is_affine) warp_accumulate_u16c3_kernel<true><<<grid, 256, 0, s>>>(a);
+        else warp_accumulate_u16c3_kernel<false><<<grid, 256, 0, s>>>(a);
         return hipGetLastError();
     }
 #define STK_WARP_CASE(T, CN) warp_accumulate_kernel<T, CN><<<grid, 256, 0, s>>>(a)
