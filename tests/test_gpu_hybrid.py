@@ -56,3 +56,23 @@ def test_hybrid_falls_back_to_identity_and_rejects_bad_input(stacker):
         stacker.hybrid_match(list(f8), KP, EccMatchParameters(MotionType.Affine, 50, 1e-5, 5))
     with pytest.raises(InvalidParams):
         stacker.hybrid_match([f.astype(np.float32) for f in f8], KP, ECC)
+
+
+def test_hybrid_shards_reproduce_the_single_gpu_stack(stacker):
+    import torch
+    from libstacker_rs_amd.shard import shard_moving_frames
+    f16, _, _ = _stack16(5, 320, 240)
+    full, full_stats = stacker.hybrid_match(list(f16), KP, ECC, return_stats=True)
+    total = torch.zeros((240, 320, 3), dtype=torch.float32, device="cuda")
+    added_total = 0
+    for rank in range(2):
+        mine = shard_moving_frames(len(f16), 2, rank)
+        acc = torch.empty_like(total)
+        added, stats = stacker.hybrid_match_shard(list(f16[[0] + mine]), KP, ECC, rank == 0, acc)
+        for j, g in enumerate(mine):
+            assert np.array_equal(stats[1 + j]["warp"], full_stats[g]["warp"])
+        total += acc
+        added_total += added
+    assert added_total == len(f16)
+    out = stacker.finalize_mean(total, added_total).cpu().numpy()
+    assert np.max(np.abs(out - full)) <= 1e-6
