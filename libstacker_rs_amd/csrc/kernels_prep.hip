@@ -80,6 +80,23 @@ __global__ __launch_bounds__(256) void grey16_to_8_kernel(const uint16_t* __rest
     for (; i < n; i += step) dst[i] = (uint8_t)(((unsigned)src[i] + 128u) / 257u);
 }
 
+// BGR 16-bit frame -> 8-bit grey in one pass: grey16 by the 16U formula, then (g + 128) / 257. Batched over frames.
+__global__ __launch_bounds__(256) void bgr16_to_grey8_kernel(const uint16_t* __restrict__ src, size_t stride, int w, int h,
+                                                             uint8_t* __restrict__ out, size_t src_frame_stride, size_t out_frame_stride) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    src += blockIdx.z * src_frame_stride; out += blockIdx.z * out_frame_stride;
+    const uint16_t* p = src + (size_t)y * stride + (size_t)x * 3;
+    out[(size_t)y * w + x] = (uint8_t)(((unsigned)grey_u16(p[0], p[1], p[2]) + 128u) / 257u);
+}
+
+hipError_t launch_bgr16_to_grey8(const void* bgr16, int w, int h, size_t stride_bytes, uint8_t* out, hipStream_t s, int n_frames,
+                                 size_t src_frame_bytes, size_t out_frame_elems) {
+    dim3 grid((w + 255) / 256, h, n_frames);
+    bgr16_to_grey8_kernel<<<grid, 256, 0, s>>>((const uint16_t*)bgr16, stride_bytes / 2, w, h, out, src_frame_bytes / 2, out_frame_elems);
+    return hipGetLastError();
+}
+
 hipError_t launch_grey16_to_8(const uint16_t* src, size_t n, uint8_t* dst, hipStream_t s) {
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 8192));
     grey16_to_8_kernel<<<blocks, 256, 0, s>>>(src, n, dst);
@@ -174,8 +191,9 @@ __global__ __launch_bounds__(256) void grey_blur_kernel(const T* __restrict__ sr
 constexpr int FB_X = 128, FB_Y = 32, FB_HX = 4;           // outputs per tile; horizontal halo loaded (>= r, multiple of 4)
 constexpr int FB_GW = FB_X + 2 * FB_HX;                   // 136 floats per grey tile row
 
-template <int R>
-__global__ __launch_bounds__(256) void grey_blur_u8c3_kernel(const uint8_t* __restrict__ src, size_t stride, int w, int h,
+// T = uint8_t (stride in bytes) or uint16_t (16-bit stacks of the hybrid path; stride in elements, rows 4-byte aligned)
+template <int R, typename T = uint8_t>
+__global__ __launch_bounds__(256) void grey_blur_u8c3_kernel(const T* __restrict__ src, size_t stride, int w, int h,
                                                              GaussTaps taps, float* __restrict__ out, int out_stride) {
     constexpr int GH = FB_Y + 2 * R;
     __shared__ __attribute__((aligned(16))) float G[GH * FB_GW];
@@ -192,21 +210,30 @@ __global__ __launch_bounds__(256) void grey_blur_u8c3_kernel(const uint8_t* __re
         const int qy = i / QW, qx = i - qy * QW;
         const int sy = reflect101(y0 - R + qy, h);
         const int sx0 = x0 - FB_HX + 4 * qx;
-        const uint8_t* row = src + (size_t)sy * stride;
+        const T* row = src + (size_t)sy * stride;
         float4 g;
         if (sx0 >= 0 && sx0 + 3 < w) {
             const uint32_t* p = reinterpret_cast<const uint32_t*>(row + (size_t)sx0 * 3);
-            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
-            g.x = (float)grey_u8(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u);
-            g.y = (float)grey_u8(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u);
-            g.z = (float)grey_u8((d1 >> 16) & 255u, d1 >> 24, d2 & 255u);
-            g.w = (float)grey_u8((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24);
+            if constexpr (sizeof(T) == 1) {
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+                g.x = (float)grey_u8(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u);
+                g.y = (float)grey_u8(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u);
+                g.z = (float)grey_u8((d1 >> 16) & 255u, d1 >> 24, d2 & 255u);
+                g.w = (float)grey_u8((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24);
+            } else {
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4], d5 = p[5];   // b0 g0 | r0 b1 | g1 r1 | b2 g2 | r2 b3 | g3 r3
+                g.x = (float)grey_u16(d0 & 0xffffu, d0 >> 16, d1 & 0xffffu);
+                g.y = (float)grey_u16(d1 >> 16, d2 & 0xffffu, d2 >> 16);
+                g.z = (float)grey_u16(d3 & 0xffffu, d3 >> 16, d4 & 0xffffu);
+                g.w = (float)grey_u16(d4 >> 16, d5 & 0xffffu, d5 >> 16);
+            }
         } else {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const uint8_t* q = row + (size_t)reflect101(sx0 + e, w) * 3;
-                v[e] = (float)grey_u8(q[0], q[1], q[2]);
+                const T* q = row + (size_t)reflect101(sx0 + e, w) * 3;
+                if constexpr (sizeof(T) == 1) v[e] = (float)grey_u8(q[0], q[1], q[2]);
+                else v[e] = (float)grey_u16(q[0], q[1], q[2]);
             }
             g = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -277,6 +304,15 @@ hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, si
         if (r == 1) grey_blur_u8c3_kernel<1><<<fgrid, 256, 0, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
         else if (r == 2) grey_blur_u8c3_kernel<2><<<fgrid, 256, 0, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
         else grey_blur_u8c3_kernel<3><<<fgrid, 256, 0, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+        return hipGetLastError();
+    }
+    if (depth == 16 && cn == 3 && r >= 1 && r <= 3 && stride_bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 &&
+        out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        dim3 fgrid((w + FB_X - 1) / FB_X, (h + FB_Y - 1) / FB_Y);
+        const uint16_t* s16 = (const uint16_t*)src;
+        if (r == 1) grey_blur_u8c3_kernel<1, uint16_t><<<fgrid, 256, 0, s>>>(s16, stride_bytes / 2, w, h, taps, out, out_stride);
+        else if (r == 2) grey_blur_u8c3_kernel<2, uint16_t><<<fgrid, 256, 0, s>>>(s16, stride_bytes / 2, w, h, taps, out, out_stride);
+        else grey_blur_u8c3_kernel<3, uint16_t><<<fgrid, 256, 0, s>>>(s16, stride_bytes / 2, w, h, taps, out, out_stride);
         return hipGetLastError();
     }
     dim3 grid((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y);

@@ -461,7 +461,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     hipStream_t s = ctx->stream;
     const int threads = ctx->opt_kp_workers;
     const bool depth16 = frames->depth == 16;
-    if (scaled || depth16) HIP_TRY(ws->gfull.reserve((size_t)w * h * (depth16 ? 2 : 1)));
+    if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
     HIP_TRY(ws->desc0.reserve(MAX_KP * 32));
     HIP_TRY(ws->desc.reserve(MAX_KP * 32 * (size_t)batch));
     HIP_TRY(ws->knn.reserve(MAX_KP * 16 * (size_t)batch));
@@ -475,11 +475,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     // grey of a frame into level 0 of pyramid `slot`, through scale_image when scaling (utils.rs:186-214)
     auto grey_level0 = [&](const void* frame, int slot) -> stk_status {
         uint8_t* l0 = ws->pyr.as<uint8_t>() + (size_t)slot * g.pyr.total;
-        if (depth16) {                                         // grey16 (16U formula) -> (g + 128) / 257
-            HIP_TRY(launch_grey(frame, 16, w, h, rb, ws->gfull.p, s));
-            HIP_TRY(launch_grey16_to_8(ws->gfull.as<uint16_t>(), (size_t)w * h, l0, s));
-            return STK_OK;
-        }
+        if (depth16) { HIP_TRY(launch_bgr16_to_grey8(frame, w, h, rb, l0, s)); return STK_OK; }   // grey16 -> (g + 128) / 257
         if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, l0, s)); return STK_OK; }
         HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->gfull.p, s));
         HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, l0, ew, eh, s));
@@ -497,10 +493,11 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     for (int b0 = 0; b0 < n; b0 += batch) {
         const int nb = std::min(batch, n - b0);
         // level 0 of every pyramid of the batch: one launch when the frames are evenly spaced in memory (a tensor), else per frame
-        bool even = !scaled && !depth16 && nb > 1;
+        bool even = !scaled && nb > 1;
         const ptrdiff_t fstep = nb > 1 ? (const uint8_t*)dev[b0 + 1] - (const uint8_t*)dev[b0] : 0;
         for (int k = 1; even && k + 1 < nb; k++) even = ((const uint8_t*)dev[b0 + k + 1] - (const uint8_t*)dev[b0 + k]) == fstep;
-        if (even && fstep > 0) HIP_TRY(launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total));
+        if (even && fstep > 0 && depth16) HIP_TRY(launch_bgr16_to_grey8(dev[b0], w, h, rb, ws->pyr.as<uint8_t>(), s, nb, (size_t)fstep, g.pyr.total));
+        else if (even && fstep > 0) HIP_TRY(launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total));
         else
             for (int k = 0; k < nb; k++)
                 if ((st = grey_level0(dev[b0 + k], k))) return st;

@@ -579,7 +579,7 @@ stk_status stk_grey_blur_f32(stk_ctx* ctx, const stk_frames* f, int32_t ksize, f
     stk_status st = check_frames(ctx, f, true);
     if (st) return st;
     if (!out) return fail(ctx, STK_INVALID_PARAMS, "null output");
-    if (f->depth != 8 && f->depth != 32) return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: images must be 8-bit or f32");
+    // (16-bit frames: only the hybrid extension runs ECC on them, on float(grey16); the stage is exposed for its tests)
     if (ksize <= 0 || ksize % 2 == 0) return fail(ctx, STK_BACKEND_ERROR, "GaussianBlur: kernel size must be odd and positive");
     if (ksize > 31) return fail(ctx, STK_NOT_IMPLEMENTED, "ksize > 31 is not supported");
     (void)hipSetDevice(ctx->device);

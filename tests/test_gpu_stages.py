@@ -64,6 +64,14 @@ def test_fused_grey_blur_bit_exact(stacker, shape, ksize):
     assert np.array_equal(dev.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("shape", [(120, 200), (97, 131)])
+def test_fused_grey_blur_u16_bit_exact(stacker, shape):
+    # 16-bit BGR (hybrid path): grey by the 16U formula, blur of float(grey16); (120,200) takes the dword-load fast path
+    img = _rng_img(shape[0], shape[1], 3, np.uint16, 12)
+    ref = oracle.gaussian_blur_f32(oracle.grey(img).astype(np.float32), 5)
+    assert np.array_equal(stacker.grey_blur_f32(img, 5), ref)
+
+
 def test_fused_grey_blur_f32_input_and_large_kernel(stacker):
     img = _rng_img(60, 90, 3, np.float32, 8)
     got = stacker.grey_blur_f32(img, 5)
