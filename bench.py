@@ -285,8 +285,9 @@ def main() -> None:
                 oracle.keypoint_match(sample, n_threads=use)
             cpu_s = time.perf_counter() - tc
             res["cpu_baseline"] = {"value": round(n_s / cpu_s, 4), "unit": "frames/s", "cores": use, "kind": "port",
-                                   "sample": f"first {n_s} frames of the same {W}x{H} stack, one oracle pass "
-                                             f"({cpu_s:.1f} s), frame-parallel OpenMP like the reference's Rayon fold"}
+                                   "sample": f"first {n_s} frames of the same {W}x{H} stack, one oracle pass ({cpu_s:.1f} s), "
+                                             + ("serial Python composition of the oracle's stages" if api == "hybrid"
+                                                else "frame-parallel OpenMP like the reference's Rayon fold")}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
