@@ -223,3 +223,18 @@ def test_frame_sharded_ranks_reproduce_the_single_gpu_stack(stacker, kp_stack):
     assert dropped_total == d_full == 1 and added_total == n - 1
     out = stacker.finalize_mean(total, added_total).cpu().numpy()
     assert np.max(np.abs(out - full)) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(128, 128), (129, 257), (127, 383), (96, 520), (161, 130), (256, 384), (70, 70), (63, 200)])
+def test_orb_tile_boundaries_bit_exact(stacker, shape):
+    # the FAST/NMS, blur and pyramid kernels work on 128 x 32 tiles with halos: sizes at, just below and just above the tile
+    # multiples (and images barely larger than the 2 x 31 px border) must give the oracle's keypoints and descriptors exactly
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    base = rng.integers(0, 256, (shape[0] // 4 + 2, shape[1] // 4 + 2), dtype=np.uint8)
+    g = np.kron(base, np.ones((4, 4), np.uint8))[: shape[0], : shape[1]]        # blocky texture: many real corners
+    g = np.clip(g.astype(np.int16) + rng.integers(-6, 7, g.shape), 0, 255).astype(np.uint8)
+    kp, de = stacker.orb_detect_and_compute(g, 4096)
+    kpo, deo = oracle.orb_detect_and_compute(g)
+    assert kp.shape == kpo.shape and np.array_equal(kp, kpo) and np.array_equal(de, deo)
+    if min(shape) > 100:
+        assert len(kp) > 50
