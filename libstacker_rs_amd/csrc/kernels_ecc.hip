@@ -11,8 +11,9 @@
 //  Variants of the pass (option `ecc_variant`; same sums, they differ in the f32 summation order only):
 //   * 3 (default, homography): ecc_iter_h8_kernel — row-factorised Hessian, lane-adjacent pixels, taps through
 //     one 32-bit offset on scalar bases, two-stage software pipeline (see the comment above that kernel).
+//     Translation / euclidean / affine: ecc_iter_affine_kernel — the same data movement with plain accumulators.
 //   * 0: direct — one wave per template row, lanes stream aligned 16-byte template quads, 66 per-lane
-//     accumulators, every tap a global gather. Used for translation / euclidean / affine.
+//     accumulators, every tap a global gather (the first version; kept as a cross-check).
 //   * 1: tiled — a workgroup walks 64x16-pixel tiles; the source footprint of a tile is copied for all three
 //     planes into LDS with LDS-DMA (global_load_lds_dwordx4), double-buffered, and every tap is an LDS read.
 //   * 2: row-sharing — the waves of a workgroup are the slots, all on the same template row.
@@ -444,6 +445,75 @@ __global__ __launch_bounds__(256, 3) void ecc_iter_h8_kernel(EccIterArgs a) {   
 }
 
 // ---------------------------------------------------------------------------------------------------
+// translation / euclidean / affine (variant 3 for these motions): the data movement of the row-factorised kernel
+// (lane-adjacent pixels, one 32-bit tap offset on scalar bases, (gx, gy) interleaved, two-stage software pipeline)
+// with the plain per-lane moment accumulators — these motions have 15 / 21 / 45 sums, so there is nothing to factorise.
+// Per-pixel arithmetic is accumulate_pixel's, i.e. identical to the direct variant up to the f32 summation order.
+// ---------------------------------------------------------------------------------------------------
+template <int MOTION>
+__global__ __launch_bounds__(256, 3) void ecc_iter_affine_kernel(EccIterArgs a) {
+    constexpr int P = MotionTraits<MOTION>::P;
+    constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
+    const int bid = (int)blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int slot = a.slot0 + q % a.n_slots;
+    const int region = (q / a.n_slots) * 8 + xcd;
+    const EccSlot* sl = a.slots + slot;
+    const int frame = sl->frame;
+    if (frame < 0) return;
+    SlotConst c;
+    load_slot_const(sl, a, c);
+    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) acc[k] = 0.f;
+    const int rs = a.ref.stride;
+    const int corner = REF_PAD * rs + REF_PAD;
+    const char* __restrict__ Ib = reinterpret_cast<const char*>(a.ref.I - corner);
+    const char* __restrict__ Gb = reinterpret_cast<const char*>(a.ref.gxy - 2 * (size_t)corner);
+    const char* __restrict__ Ib1 = Ib + (size_t)rs * 4;
+    const char* __restrict__ Gb1 = Gb + (size_t)rs * 8;
+    const int nchunk = (a.tw + 63) >> 6;
+    for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
+        const float fy = (float)y;
+        const float rowX = __builtin_fmaf(c.m1, fy, c.m2), rowY = __builtin_fmaf(c.m4, fy, c.m5);
+        const float* trow = T + (size_t)y * a.templ_row_stride;
+        auto stage_a = [&](int x, H8Px& p) {
+            const int xc = min(x, a.tw - 1);                  // past the row end: a harmless repeat, skipped in stage B
+            p.x = x;
+            p.tval = trow[xc];
+            const float fx = (float)xc;
+            const float sx = __builtin_fmaf(c.m0, fx, rowX), sy = __builtin_fmaf(c.m3, fx, rowY);
+            p.sx = sx; p.sy = sy; p.rw = 1.0f;
+            const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
+            p.ax = sx - flx; p.ay = sy - fly;
+            const int ix = (int)__builtin_amdgcn_fmed3f(flx, -2.0f, c.fiw);
+            const int iy = (int)__builtin_amdgcn_fmed3f(fly, -2.0f, c.fih);
+            const unsigned bo = (unsigned)(__mul24(iy, rs) + ix + corner) << 2;
+            p.i0 = *(const f32x2_a4*)(Ib + bo); p.i1 = *(const f32x2_a4*)(Ib1 + bo);
+            p.g0 = *(const f32x4_a8*)(Gb + 2u * bo); p.g1 = *(const f32x4_a8*)(Gb1 + 2u * bo);
+        };
+        auto stage_b = [&](const H8Px& p) {
+            if (p.x >= a.tw) return;
+            const float Iw = bilerp4(p.i0.x, p.i0.y, p.i1.x, p.i1.y, p.ax, p.ay);
+            const float gxw = bilerp4(p.g0.x, p.g0.z, p.g1.x, p.g1.z, p.ax, p.ay);
+            const float gyw = bilerp4(p.g0.y, p.g0.w, p.g1.y, p.g1.w, p.ax, p.ay);
+            accumulate_pixel<MOTION, NS>(c, sl->warp, p.x, y, (float)p.x, fy, p.sx, p.sy, 1.0f, 0.0f, 0.0f, Iw, gxw, gyw, p.tval, acc);
+        };
+        H8Px p0, p1;
+        stage_a(lane, p0);
+        for (int k = 0; k < nchunk; k += 2) {
+            stage_a((k + 1) * 64 + lane, p1);
+            stage_b(p0);
+            stage_a((k + 2) * 64 + lane, p0);
+            stage_b(p1);
+        }
+    }
+    block_reduce_store<NS>(acc, a, slot, region);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // row-sharing variant: the waves of a workgroup are the SLOTS. All of them process the same template
 // row at the same time on the same CU, each with its own frame and warp, so the frame-0 taps that
 // the near-identical warps share are fetched once and then hit in that CU's L1 (measured with the
@@ -660,9 +730,15 @@ __global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
 
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
-    if (variant == 3 && motion == STK_MOTION_HOMOGRAPHY) {   // other motions: direct variant below
+    if (variant == 3) {
         if (grid <= 0) return hipSuccess;
-        ecc_iter_h8_kernel<<<grid, 256, 0, s>>>(a);
+        switch (motion) {
+            case STK_MOTION_HOMOGRAPHY: ecc_iter_h8_kernel<<<grid, 256, 0, s>>>(a); break;
+            case STK_MOTION_AFFINE: ecc_iter_affine_kernel<STK_MOTION_AFFINE><<<grid, 256, 0, s>>>(a); break;
+            case STK_MOTION_EUCLIDEAN: ecc_iter_affine_kernel<STK_MOTION_EUCLIDEAN><<<grid, 256, 0, s>>>(a); break;
+            case STK_MOTION_TRANSLATION: ecc_iter_affine_kernel<STK_MOTION_TRANSLATION><<<grid, 256, 0, s>>>(a); break;
+            default: return hipErrorInvalidValue;
+        }
         return hipGetLastError();
     }
     if (variant == 2) {     // one workgroup = n_slots waves; a.nb workgroups in total (multiple of 8)
