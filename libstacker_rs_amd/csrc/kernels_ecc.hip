@@ -17,9 +17,10 @@
 //   * 1: tiled — a workgroup walks 64x16-pixel tiles; the source footprint of a tile is copied for all three
 //     planes into LDS with LDS-DMA (global_load_lds_dwordx4), double-buffered, and every tap is an LDS read.
 //   * 2: row-sharing — the waves of a workgroup are the slots, all on the same template row.
-//  Measured: the pass is NOT HBM-bound (fabric traffic < algorithmic bytes: frame 0 is shared in
-//  L2/MALL); variants 1 and 2 and template prefetch left the time unchanged, removing VALU instructions scaled it
-//  proportionally, contiguous gathers and pipelining the loads bought the rest. 182 -> 100 us per 4-slot 4K launch.
+//  Measured: fabric traffic per launch equals the algorithmic bytes (no re-reads); ablations put the
+//  arithmetic alone at 107 us and the coordinate + gather side alone at 86 us of a 116 us full 4-slot 4K launch.
+//  Variants 1 and 2 and template prefetch left the time unchanged; removing VALU instructions, contiguous gathers and
+//  pipelining the loads bought the rest. 182 -> 98 us per 4-slot 4K launch over round 1.
 //
 //  Several frames ("slots") iterate concurrently in one launch. blockIdx is decoded so that the
 //  blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD and
