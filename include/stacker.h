@@ -196,9 +196,10 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
                                   int32_t* n_added, stk_frame_stats* stats);
 
 /* ---- file front-end ---------------------------------------------------------
- * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit): BGR or grey
- * rows, tightly packed, into `data` (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.
- * Formats that need an external codec (JPEG, PNG, TIFF ...) -> STK_NOT_IMPLEMENTED; unreadable / not an image ->
+ * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit) and 8-bit
+ * RGB / grey PNG (when libpng16.so.16 can be loaded at run time): BGR or grey rows, tightly packed, into `data`
+ * (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.
+ * Other formats (JPEG, TIFF, PNG with alpha / 16 bit / palette ...) -> STK_NOT_IMPLEMENTED; unreadable / not an image ->
  * STK_BACKEND_ERROR, as the reference's empty Mat + cvtColor does. */
 stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width,
                       int32_t* height, int32_t* channels, int32_t* depth);

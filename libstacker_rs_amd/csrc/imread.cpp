@@ -1,10 +1,14 @@
 // imread.cpp — the file front-end of the reference's entry points: `imgcodecs::imread(path,
 // IMREAD_UNCHANGED)` (utils.rs:110-117, 132) for the one family of formats this build can decode without external codec
 // libraries — binary PNM (P5 grey, P6 colour; 8 or 16 bit) — and keypoint_match / ecc_match in the reference's own call
-// shape, a list of paths (lib.rs:129-137, 702-710). JPEG / PNG / TIFF need libjpeg / libpng / libtiff, whose headers
-// are not in this image: those paths return STK_NOT_IMPLEMENTED and the caller decodes them itself (the frame-based
-// entry points are the boundary). A file that is missing or not an image behaves as in the reference: imread gives an
+// shape, a list of paths (lib.rs:129-137, 702-710). 8-bit RGB / grey PNG is decoded through libpng's simplified API when
+// libpng16.so.16 can be loaded at run time (it is installed in the image, its headers are not: the four entry points and
+// the png_image struct of png.h 1.6 are declared below). JPEG / TIFF / other PNG flavours (alpha, 16-bit, palette) return
+// STK_NOT_IMPLEMENTED and the caller decodes them itself (the frame-based entry points are the boundary). A file that is missing or not an image behaves as in the reference: imread gives an
 // empty Mat and the following cvtColor raises -> STK_BACKEND_ERROR (OpenCvError).
+#include <dlfcn.h>
+
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -80,10 +84,62 @@ void pnm_decode(const unsigned char* raster, const Pnm& p, void* dst) {
     }
 }
 
-// 0 ok; else a status with the message set
+// ---- PNG through libpng 1.6's simplified API, resolved at run time ------------------------------------------
+struct PngImage {            // png_image of png.h (libpng 1.6, PNG_IMAGE_VERSION 1)
+    void* opaque;
+    uint32_t version, width, height, format, flags, colormap_entries, warning_or_error;
+    char message[64];
+};
+constexpr uint32_t PNG_FMT_GRAY = 0x00, PNG_FMT_RGB = 0x02, PNG_FMT_BGR = 0x12;   // COLOR = 0x02, BGR = 0x10
+
+struct PngApi {
+    int (*begin_read_from_file)(PngImage*, const char*) = nullptr;
+    int (*finish_read)(PngImage*, const void* background, void* buffer, int32_t row_stride, void* colormap) = nullptr;
+    void (*image_free)(PngImage*) = nullptr;
+    bool ok = false;
+};
+
+const PngApi& png_api() {
+    static const PngApi api = []() {
+        PngApi a;
+        void* h = dlopen("libpng16.so.16", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.begin_read_from_file = reinterpret_cast<int (*)(PngImage*, const char*)>(dlsym(h, "png_image_begin_read_from_file"));
+        a.finish_read = reinterpret_cast<int (*)(PngImage*, const void*, void*, int32_t, void*)>(dlsym(h, "png_image_finish_read"));
+        a.image_free = reinterpret_cast<void (*)(PngImage*)>(dlsym(h, "png_image_free"));
+        a.ok = a.begin_read_from_file && a.finish_read && a.image_free;
+        return a;
+    }();
+    return api;
+}
+
+// 0 decoded into pix (BGR or grey, 8 bit); 1 not decodable (read error); 2 a PNG flavour this build does not take
+int png_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
+    const PngApi& api = png_api();
+    if (!api.ok) return 2;
+    PngImage im;
+    std::memset(&im, 0, sizeof im);
+    im.version = 1;
+    if (!api.begin_read_from_file(&im, path)) { api.image_free(&im); return 1; }
+    if (im.format != PNG_FMT_RGB && im.format != PNG_FMT_GRAY) { api.image_free(&im); return 2; }   // alpha / 16-bit / palette
+    p.w = (int)im.width; p.h = (int)im.height; p.cn = im.format == PNG_FMT_RGB ? 3 : 1; p.depth = 8; p.data_ofs = 0;
+    if (im.format == PNG_FMT_RGB) im.format = PNG_FMT_BGR;      // imread returns BGR
+    pix.resize((size_t)p.w * p.h * p.cn);
+    if (!api.finish_read(&im, nullptr, pix.data(), 0, nullptr)) { api.image_free(&im); return 1; }
+    return 0;                                                     // finish_read frees the image on success
+}
+
+// 0 ok; else a status with the message set. PNM: `file` holds the file, raster at p.data_ofs; PNG: `file` holds the decoded pixels.
 stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>& file, Pnm& p) {
     if (!path) return fail(ctx, STK_INVALID_PARAMS, "null path");
-    for (const char* e : {".jpg", ".jpeg", ".jpe", ".png", ".tif", ".tiff", ".bmp", ".webp", ".exr"})
+    if (has_ext(path, ".png")) {
+        const int rc = png_load(path, p, file);
+        if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }                      // already decoded
+        if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only 8-bit RGB / grey PNG without alpha is decoded in this "
+                                              "build (libpng16.so.16 " + (png_api().ok ? "loaded" : "not found") + ")");
+    }
+    for (const char* e : {".jpg", ".jpeg", ".jpe", ".tif", ".tiff", ".bmp", ".webp", ".exr"})
         if (has_ext(path, e))
             return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: no codec for '") + path + "' in this build (binary PNM only); decode it "
                                                   "on the caller's side and use the frame-based entry points");
@@ -111,8 +167,11 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
         if (i == 0) first = p;
         else if (p.w != first.w || p.h != first.h || p.cn != first.cn || p.depth != first.depth)
             return fail(ctx, STK_INVALID_PARAMS, std::string("'") + paths[i] + "' differs in size or type from the first frame");
-        pix[i].resize((size_t)p.w * p.h * p.cn * (p.depth / 8));
-        pnm_decode(file.data() + p.data_ofs, p, pix[i].data());
+        if (p.data_ofs == (size_t)-1) pix[i].swap(file);             // PNG: already decoded
+        else {
+            pix[i].resize((size_t)p.w * p.h * p.cn * (p.depth / 8));
+            pnm_decode(file.data() + p.data_ofs, p, pix[i].data());
+        }
         ptrs[i] = pix[i].data();
     }
     stk_frames fr{};
@@ -138,7 +197,8 @@ stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacit
     if (!data) return STK_OK;                                  // geometry query
     const size_t need = (size_t)p.w * p.h * p.cn * (p.depth / 8);
     if (capacity_bytes < need) return fail(ctx, STK_INVALID_PARAMS, "imread: output buffer too small");
-    pnm_decode(file.data() + p.data_ofs, p, data);
+    if (p.data_ofs == (size_t)-1) std::memcpy(data, file.data(), need);   // PNG: already decoded
+    else pnm_decode(file.data() + p.data_ofs, p, data);
     return STK_OK;
 }
 

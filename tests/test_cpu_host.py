@@ -171,4 +171,36 @@ def test_imread_pnm_without_a_gpu(tmp_path):
     assert np.array_equal(out, img)
     assert lib.stk_imread(None, os.fsencode(p), C.c_void_p(out.ctypes.data), 10, None, None, None, None) == 2      # INVALID_PARAMS
     assert lib.stk_imread(None, os.fsencode(tmp_path / "nope.ppm"), None, 0, None, None, None, None) == 4         # BACKEND_ERROR
-    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), None, 0, None, None, None, None) == 7            # NOT_IMPLEMENTED
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.jpg"), None, 0, None, None, None, None) == 7            # NOT_IMPLEMENTED
+
+
+def test_imread_png_through_runtime_libpng(tmp_path, write_png):
+    """8-bit RGB / grey PNG via libpng's simplified API loaded at run time (no headers in the image); other flavours
+    and a missing libpng -> NOT_IMPLEMENTED."""
+    import ctypes.util
+    lib = _ffi.load()
+    rng = np.random.default_rng(1)
+    bgr = rng.integers(0, 256, (13, 21, 3), dtype=np.uint8)
+    grey = rng.integers(0, 256, (8, 5), dtype=np.uint8)
+    write_png(tmp_path / "c.png", bgr)
+    write_png(tmp_path / "g.png", grey)
+    write_png(tmp_path / "a.png", rng.integers(0, 256, (4, 4, 4), dtype=np.uint8))
+    w, h, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    st = lib.stk_imread(None, os.fsencode(tmp_path / "c.png"), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d))
+    try:
+        have_png = C.CDLL("libpng16.so.16") is not None
+    except OSError:
+        have_png = False
+    if not have_png:
+        assert st == 7
+        return
+    assert st == 0 and (w.value, h.value, c.value, d.value) == (21, 13, 3, 8)
+    out = np.empty_like(bgr)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "c.png"), C.c_void_p(out.ctypes.data), out.nbytes, None, None, None, None) == 0
+    assert np.array_equal(out, bgr)                              # RGB on disk -> BGR in memory, like imread
+    og = np.empty_like(grey)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "g.png"), C.c_void_p(og.ctypes.data), og.nbytes, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+    assert c.value == 1 and np.array_equal(og, grey)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), None, 0, None, None, None, None) == 7       # alpha: not taken
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n garbage")
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "bad.png"), None, 0, None, None, None, None) == 4     # BACKEND_ERROR

@@ -70,3 +70,21 @@ def test_path_based_entry_points_equal_frame_based(stacker, tmp_path):
         stacker.keypoint_match_files([tmp_path / "a16.ppm", tmp_path / "b16.ppm"], kp)
     with pytest.raises(OpenCvError):
         stacker.ecc_match_files([tmp_path / "a16.ppm", tmp_path / "b16.ppm"], ecc)
+
+
+def test_png_paths_equal_frame_based(stacker, tmp_path, write_png):
+    # 8-bit RGB PNG through the run-time libpng (where it can be loaded): same result as handing the frames over
+    import ctypes
+    try:
+        ctypes.CDLL("libpng16.so.16")
+    except OSError:
+        pytest.skip("libpng16.so.16 is not installed here")
+    frames, _ = synth.make_stack(3, 320, 240)
+    fr = frames.numpy()
+    paths = []
+    for i, f in enumerate(fr):
+        paths.append(tmp_path / f"frame_{i}.png")
+        write_png(paths[-1], f)
+    assert np.array_equal(stacker.imread(paths[1]), fr[1])
+    ecc = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
+    assert np.array_equal(stacker.ecc_match_files(paths, ecc), stacker.ecc_match(list(fr), ecc))
