@@ -196,10 +196,11 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
                                   int32_t* n_added, stk_frame_stats* stats);
 
 /* ---- file front-end ---------------------------------------------------------
- * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit) and 8-bit
- * RGB / grey PNG (when libpng16.so.16 can be loaded at run time): BGR or grey rows, tightly packed, into `data`
+ * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit), 8-bit
+ * RGB / grey PNG and stripped 8/16-bit grey / RGB TIFF (the latter two when libpng16.so.16 / libtiff.so.5 can be loaded
+ * at run time): BGR or grey rows, tightly packed, into `data`
  * (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.
- * Other formats (JPEG, TIFF, PNG with alpha / 16 bit / palette ...) -> STK_NOT_IMPLEMENTED; unreadable / not an image ->
+ * Other formats (JPEG, tiled TIFF, PNG with alpha / 16 bit / palette ...) -> STK_NOT_IMPLEMENTED; unreadable / not an image ->
  * STK_BACKEND_ERROR, as the reference's empty Mat + cvtColor does. */
 stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width,
                       int32_t* height, int32_t* channels, int32_t* depth);
@@ -209,6 +210,9 @@ stk_status stk_keypoint_match_files(stk_ctx* ctx, const char* const* paths, int3
                                     float scale_down_width, stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats);
 stk_status stk_ecc_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_ecc_params* params,
                                float scale_down_width, stk_image_f32* out, stk_frame_stats* stats);
+/* stk_hybrid_match on a list of paths (8-bit PNM / PNG / TIFF, 16-bit PNM / TIFF). */
+stk_status stk_hybrid_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_keypoint_params* kp_params,
+                                  const stk_ecc_params* ecc_params, stk_image_f32* out, stk_frame_stats* stats);
 
 /* sharpness_modified_laplacian / _variance_of_laplacian / _tenengrad(k_size) / _normalized_gray_level_variance
  * (lib.rs:1030-1166; the pre-filter of examples/main.rs:40-47) of a single-channel 8-bit or f32 image, tightly packed.

@@ -81,6 +81,8 @@ SIGNATURES = {
                                             C.POINTER(ImageF32), C.POINTER(C.c_int32), C.POINTER(FrameStats)]),
     "stk_ecc_match_files": (c_status, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(EccParams), C.c_float,
                                        C.POINTER(ImageF32), C.POINTER(FrameStats)]),
+    "stk_hybrid_match_files": (c_status, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(KeypointParams),
+                                          C.POINTER(EccParams), C.POINTER(ImageF32), C.POINTER(FrameStats)]),
     "stk_sharpness": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(C.c_double)]),
     "stk_grey_blur_f32": (c_status, [C.c_void_p, C.POINTER(Frames), C.c_int32, C.c_void_p]),

@@ -363,7 +363,7 @@ class Stacker:
 
     # -- file front-end: the reference's entry points take paths ------------------------------
     def imread(self, path):
-        """imgcodecs::imread(path, IMREAD_UNCHANGED) for binary PNM (P5 / P6, 8 or 16 bit): HxW or HxWx3 (BGR) array."""
+        """imgcodecs::imread(path, IMREAD_UNCHANGED) for binary PNM, 8-bit PNG and 8/16-bit TIFF: HxW or HxWx3 (BGR) array."""
         w, h, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
         bp = os.fsencode(path)
         self._check(self._lib.stk_imread(self._h, bp, None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)))
@@ -408,6 +408,19 @@ class Stacker:
         p = params._c()
         self._check(self._lib.stk_ecc_match_files(self._h, arr, len(files), C.byref(p), float(scale_down_width or 0.0),
                                                   C.byref(img), None))
+        return out
+
+    def hybrid_match_files(self, files, kp_params: KeyPointMatchParameters, ecc_params: EccMatchParameters):
+        """stk_hybrid_match on a list of paths (e.g. a 16-bit TIFF stack)."""
+        files = list(files)
+        if not files:
+            raise NotEnoughFiles("Not enough files")
+        w, h = self._file_geometry(files)
+        out = np.empty((h, w, 3), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w, h, 3, HOST, 0)
+        keep, arr = self._paths(files)
+        kp, ep = kp_params._c(), ecc_params._c()
+        self._check(self._lib.stk_hybrid_match_files(self._h, arr, len(files), C.byref(kp), C.byref(ep), C.byref(img), None))
         return out
 
     def _sharpness(self, grey, metric: int, ksize: int = 0) -> float:

@@ -4,7 +4,8 @@
 // shape, a list of paths (lib.rs:129-137, 702-710). 8-bit RGB / grey PNG is decoded through libpng's simplified API when
 // libpng16.so.16 can be loaded at run time (it is installed in the image, its headers are not: the four entry points and
 // the png_image struct of png.h 1.6 are declared below). JPEG / TIFF / other PNG flavours (alpha, 16-bit, palette) return
-// STK_NOT_IMPLEMENTED and the caller decodes them itself (the frame-based entry points are the boundary). A file that is missing or not an image behaves as in the reference: imread gives an
+// STK_NOT_IMPLEMENTED and the caller decodes them itself (the frame-based entry points are the boundary). Stripped 8/16-bit
+// grey / RGB TIFF goes through libtiff's handle-based API (TIFFOpen / TIFFGetField / TIFFReadScanline), loaded the same way. A file that is missing or not an image behaves as in the reference: imread gives an
 // empty Mat and the following cvtColor raises -> STK_BACKEND_ERROR (OpenCvError).
 #include <dlfcn.h>
 
@@ -129,6 +130,74 @@ int png_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
     return 0;                                                     // finish_read frees the image on success
 }
 
+// ---- TIFF through libtiff's handle-based API, resolved at run time (no struct layouts involved) --------------------
+struct TiffApi {
+    void* (*open)(const char*, const char*) = nullptr;
+    void (*close)(void*) = nullptr;
+    int (*get_field)(void*, uint32_t, ...) = nullptr;
+    int (*read_scanline)(void*, void*, uint32_t, uint16_t) = nullptr;
+    long (*scanline_size)(void*) = nullptr;
+    int (*is_tiled)(void*) = nullptr;
+    void* (*set_error_handler)(void*) = nullptr;
+    void* (*set_warning_handler)(void*) = nullptr;
+    bool ok = false;
+};
+
+const TiffApi& tiff_api() {
+    static const TiffApi api = []() {
+        TiffApi a;
+        void* h = dlopen("libtiff.so.5", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libtiff.so.6", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.open = reinterpret_cast<void* (*)(const char*, const char*)>(dlsym(h, "TIFFOpen"));
+        a.close = reinterpret_cast<void (*)(void*)>(dlsym(h, "TIFFClose"));
+        a.get_field = reinterpret_cast<int (*)(void*, uint32_t, ...)>(dlsym(h, "TIFFGetField"));
+        a.read_scanline = reinterpret_cast<int (*)(void*, void*, uint32_t, uint16_t)>(dlsym(h, "TIFFReadScanline"));
+        a.scanline_size = reinterpret_cast<long (*)(void*)>(dlsym(h, "TIFFScanlineSize"));
+        a.is_tiled = reinterpret_cast<int (*)(void*)>(dlsym(h, "TIFFIsTiled"));
+        a.set_error_handler = reinterpret_cast<void* (*)(void*)>(dlsym(h, "TIFFSetErrorHandler"));
+        a.set_warning_handler = reinterpret_cast<void* (*)(void*)>(dlsym(h, "TIFFSetWarningHandler"));
+        a.ok = a.open && a.close && a.get_field && a.read_scanline && a.scanline_size && a.is_tiled;
+        if (a.ok && a.set_error_handler && a.set_warning_handler) { a.set_error_handler(nullptr); a.set_warning_handler(nullptr); }   // quiet
+        return a;
+    }();
+    return api;
+}
+
+// 8- or 16-bit, grey (MINISBLACK) or RGB, contiguous, stripped TIFF (any compression libtiff handles) -> grey / BGR
+// 0 decoded; 1 not decodable; 2 a flavour this build does not take
+int tiff_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
+    const TiffApi& api = tiff_api();
+    if (!api.ok) return 2;
+    void* t = api.open(path, "r");
+    if (!t) return 1;
+    uint32_t w = 0, h = 0;
+    uint16_t bps = 1, spp = 1, photo = 0, planar = 1;
+    api.get_field(t, 256, &w); api.get_field(t, 257, &h);                  // IMAGEWIDTH, IMAGELENGTH
+    api.get_field(t, 258, &bps); api.get_field(t, 277, &spp);              // BITSPERSAMPLE, SAMPLESPERPIXEL
+    api.get_field(t, 262, &photo); api.get_field(t, 284, &planar);         // PHOTOMETRIC, PLANARCONFIG
+    const bool grey = spp == 1 && photo == 1, rgb = spp == 3 && photo == 2;
+    if (w == 0 || h == 0 || (bps != 8 && bps != 16) || (!grey && !rgb) || planar != 1 || api.is_tiled(t)) { api.close(t); return 2; }
+    p.w = (int)w; p.h = (int)h; p.cn = rgb ? 3 : 1; p.depth = bps; p.data_ofs = 0;
+    const size_t row = (size_t)w * p.cn * (bps / 8);
+    if ((size_t)api.scanline_size(t) < row) { api.close(t); return 1; }
+    pix.resize(row * h);
+    std::vector<unsigned char> line((size_t)api.scanline_size(t));
+    for (uint32_t y = 0; y < h; y++) {
+        if (api.read_scanline(t, line.data(), y, 0) < 0) { api.close(t); return 1; }
+        unsigned char* o = pix.data() + row * y;
+        if (!rgb) std::memcpy(o, line.data(), row);
+        else if (bps == 8) for (uint32_t x = 0; x < w; x++) { o[3 * x] = line[3 * x + 2]; o[3 * x + 1] = line[3 * x + 1]; o[3 * x + 2] = line[3 * x]; }
+        else {
+            const uint16_t* s16 = reinterpret_cast<const uint16_t*>(line.data());   // libtiff returns native byte order
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
+            for (uint32_t x = 0; x < w; x++) { o16[3 * x] = s16[3 * x + 2]; o16[3 * x + 1] = s16[3 * x + 1]; o16[3 * x + 2] = s16[3 * x]; }
+        }
+    }
+    api.close(t);
+    return 0;
+}
+
 // 0 ok; else a status with the message set. PNM: `file` holds the file, raster at p.data_ofs; PNG: `file` holds the decoded pixels.
 stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>& file, Pnm& p) {
     if (!path) return fail(ctx, STK_INVALID_PARAMS, "null path");
@@ -139,7 +208,14 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
         return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only 8-bit RGB / grey PNG without alpha is decoded in this "
                                               "build (libpng16.so.16 " + (png_api().ok ? "loaded" : "not found") + ")");
     }
-    for (const char* e : {".jpg", ".jpeg", ".jpe", ".tif", ".tiff", ".bmp", ".webp", ".exr"})
+    if (has_ext(path, ".tif") || has_ext(path, ".tiff")) {
+        const int rc = tiff_load(path, p, file);
+        if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }
+        if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only stripped 8/16-bit grey or RGB TIFF is decoded in this "
+                                              "build (libtiff " + (tiff_api().ok ? "loaded" : "not found") + ")");
+    }
+    for (const char* e : {".jpg", ".jpeg", ".jpe", ".bmp", ".webp", ".exr"})
         if (has_ext(path, e))
             return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: no codec for '") + path + "' in this build (binary PNM only); decode it "
                                                   "on the caller's side and use the frame-based entry points");
@@ -210,6 +286,12 @@ stk_status stk_keypoint_match_files(stk_ctx* ctx, const char* const* paths, int3
 stk_status stk_ecc_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_ecc_params* params,
                                float scale_down_width, stk_image_f32* out, stk_frame_stats* stats) {
     return match_files(ctx, paths, n, [&](const stk_frames* fr) { return stk_ecc_match(ctx, fr, params, scale_down_width, out, stats); });
+}
+
+
+stk_status stk_hybrid_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_keypoint_params* kp_params,
+                                  const stk_ecc_params* ecc_params, stk_image_f32* out, stk_frame_stats* stats) {
+    return match_files(ctx, paths, n, [&](const stk_frames* fr) { return stk_hybrid_match(ctx, fr, kp_params, ecc_params, out, stats); });
 }
 
 }  // extern "C"

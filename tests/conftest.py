@@ -51,3 +51,36 @@ def _write_png(path, img):
 def write_png():
     """Writer of small test PNGs (no Pillow in the main interpreter)."""
     return _write_png
+
+
+def _write_tiff(path, img):
+    """Minimal baseline TIFF writer: little-endian, uncompressed, one strip; 8/16-bit grey (HxW) or RGB (HxWx3 given as BGR)."""
+    import struct
+    a = np.asarray(img)
+    assert a.dtype in (np.uint8, np.uint16)
+    if a.ndim == 3:
+        a = a[..., ::-1]
+    h, w = a.shape[:2]
+    spp = 1 if a.ndim == 2 else 3
+    bps = a.dtype.itemsize * 8
+    data = np.ascontiguousarray(a).astype("<u%d" % a.dtype.itemsize).tobytes()
+    n_tags = 10
+    ifd_ofs = 8
+    bps_ofs = ifd_ofs + 2 + 12 * n_tags + 4
+    data_ofs = bps_ofs + 8
+    def tag(t, typ, count, value):
+        return struct.pack("<HHII", t, typ, count, value)
+    ifd = struct.pack("<H", n_tags)
+    ifd += tag(256, 4, 1, w) + tag(257, 4, 1, h)
+    ifd += tag(258, 3, spp, bps_ofs if spp == 3 else bps)
+    ifd += tag(259, 3, 1, 1) + tag(262, 3, 1, 2 if spp == 3 else 1)
+    ifd += tag(273, 4, 1, data_ofs) + tag(277, 3, 1, spp) + tag(278, 4, 1, h) + tag(279, 4, 1, len(data)) + tag(284, 3, 1, 1)
+    ifd += struct.pack("<I", 0)
+    with open(path, "wb") as f:
+        f.write(b"II" + struct.pack("<HI", 42, ifd_ofs) + ifd + struct.pack("<HHHH", bps, bps, bps, 0) + data)
+
+
+@pytest.fixture(scope="session")
+def write_tiff():
+    """Writer of small test TIFFs (no Pillow in the main interpreter)."""
+    return _write_tiff

@@ -204,3 +204,24 @@ def test_imread_png_through_runtime_libpng(tmp_path, write_png):
     assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), None, 0, None, None, None, None) == 7       # alpha: not taken
     (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n garbage")
     assert lib.stk_imread(None, os.fsencode(tmp_path / "bad.png"), None, 0, None, None, None, None) == 4     # BACKEND_ERROR
+
+
+def test_imread_tiff_through_runtime_libtiff(tmp_path, write_tiff):
+    """Stripped 8/16-bit grey / RGB TIFF via libtiff loaded at run time: what a 16-bit stack (BASELINE configs[4]) arrives as."""
+    lib = _ffi.load()
+    try:
+        C.CDLL("libtiff.so.5")
+    except OSError:
+        pytest.skip("libtiff.so.5 is not installed here")
+    rng = np.random.default_rng(2)
+    for name, img in (("c16.tif", rng.integers(0, 65536, (9, 14, 3), dtype=np.uint16)), ("c8.tiff", rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)),
+                      ("g16.tif", rng.integers(0, 65536, (6, 4), dtype=np.uint16)), ("g8.tif", rng.integers(0, 256, (3, 11), dtype=np.uint8))):
+        write_tiff(tmp_path / name, img)
+        w, h, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.stk_imread(None, os.fsencode(tmp_path / name), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+        assert (h.value, w.value) == img.shape[:2] and c.value == (1 if img.ndim == 2 else 3) and d.value == img.dtype.itemsize * 8
+        out = np.empty_like(img)
+        assert lib.stk_imread(None, os.fsencode(tmp_path / name), C.c_void_p(out.ctypes.data), out.nbytes, None, None, None, None) == 0
+        assert np.array_equal(out, img)
+    (tmp_path / "bad.tif").write_bytes(b"II*\x00 not really a tiff")
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "bad.tif"), None, 0, None, None, None, None) == 4

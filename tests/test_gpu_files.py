@@ -88,3 +88,24 @@ def test_png_paths_equal_frame_based(stacker, tmp_path, write_png):
     assert np.array_equal(stacker.imread(paths[1]), fr[1])
     ecc = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
     assert np.array_equal(stacker.ecc_match_files(paths, ecc), stacker.ecc_match(list(fr), ecc))
+
+
+def test_16bit_tiff_stack_through_hybrid_match_files(stacker, tmp_path, write_tiff):
+    # BASELINE configs[4] end to end: a 16-bit TIFF stack on disk -> ORB-seeded ECC -> f32 image
+    import ctypes
+    try:
+        ctypes.CDLL("libtiff.so.5")
+    except OSError:
+        pytest.skip("libtiff.so.5 is not installed here")
+    frames, _ = synth.make_stack(3, 320, 240)
+    f16 = frames.numpy().astype(np.uint16) * 257 + 3
+    paths = []
+    for i, f in enumerate(f16):
+        paths.append(tmp_path / f"frame_{i}.tif")
+        write_tiff(paths[-1], f)
+    assert np.array_equal(stacker.imread(paths[2]), f16[2])
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    ecc = EccMatchParameters(MotionType.Homography, 200, 1e-5, 5)
+    assert np.array_equal(stacker.hybrid_match_files(paths, kp, ecc), stacker.hybrid_match(list(f16), kp, ecc))
+    with pytest.raises(OpenCvError):                        # the reference's own entry points reject 16-bit stacks
+        stacker.ecc_match_files(paths, ecc)
