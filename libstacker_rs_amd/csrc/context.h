@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.h"
+#include "homography.h"
 #include "keypoint.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -45,6 +46,7 @@ struct stk_ctx {
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
     stk::KeypointWorkspace* kp = nullptr;
+    stk::geom::HgWorkspace* hg = nullptr;   // findHomography batch workspace (homography.cpp)
     stk::HostPool* host_pool = nullptr;   // persistent host threads of the keypoint path (keypoint.cpp)
     std::mutex err_mutex;
 };

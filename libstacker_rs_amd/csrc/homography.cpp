@@ -1,388 +1,297 @@
-// homography.cpp — host-side geometry of the keypoint path:
-// calib3d::find_homography as libstacker calls it (lib.rs:267-276): RANSAC (cv::RNG sampling,
-// subset checks, normalised DLT through a Jacobi eigen-decomposition, f32 reprojection test,
-// adaptive iteration count) or plain least squares, then DLT on the inliers and the 10-iteration
-// Levenberg-Marquardt refinement. At most a few hundred correspondences per frame in f64: this is
-// microseconds of scalar work and stays on the host (no GPU reshaping of tiny problems).
-// OpenCV sources restated [OCV-RECALL]: calib3d/src/fundam.cpp, ptsetreg.cpp, levmarq.cpp,
-// core/src/lapack.cpp (JacobiImpl_), core/src/rand.cpp.
+// homography.cpp — host driver of calib3d::findHomography (lib.rs:267-276) for a batch of frames.
+//
+// What stays on the host is only what is inherently sequential and tiny: cv::RNG's multiply-with-carry stream, the
+// sample admissibility test (collinearity + orientation, HomographyEstimatorCallback::checkSubset), and the replay of
+// RANSAC's best-so-far / RANSACUpdateNumIters (or LMEDS's least-median) decision over the per-model scores that
+// kernels_homography.hip computes. Models are evaluated speculatively in rounds (32, then 256, then the rest of the 2000):
+// with the usual > 80 % inlier ratios the adaptive iteration count collapses below 32 after the first good model, so one
+// launch covers every frame of the shard; frames that need more iterations simply take part in the next round.
+// OpenCV sources this follows [OCV-RECALL]: calib3d/src/ptsetreg.cpp (RANSACPointSetRegistrator, LMeDSPointSetRegistrator),
+// fundam.cpp (checkSubset, findHomography's final DLT + LM on the inliers), core/src/rand.cpp.
 #include "homography.h"
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
-#include <limits>
 #include <vector>
+
+#include "context.h"
 
 namespace stk {
 namespace geom {
 
-static inline int cv_round(double v) { return (int)std::lrint(v); }
-
-
-// ---- cv::RNG (multiply-with-carry) ---------------------------------------------------------------
-struct Rng {
-    uint64_t state;
-    explicit Rng(uint64_t s) : state(s ? s : 0xffffffffull) {}
-    unsigned next() { state = (uint64_t)(unsigned)state * 4164903690u + (unsigned)(state >> 32); return (unsigned)state; }
-    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+struct HgWorkspace {
+    DevBuf pts, frames, samples, scores, err, jobs, results, masks;
+    void* pinned = nullptr;          // host staging for everything that crosses PCIe in a round
+    size_t pinned_cap = 0;
 };
 
-// ---- symmetric eigen-decomposition, cv::eigen -> JacobiImpl_<double> ----------------------------------
-// eigenvalues descending in W, eigenvectors in the ROWS of V.
-void jacobi(double* A, int n, double* W, double* V) {
-    const double eps = DBL_EPSILON;
-    std::vector<int> indR(n), indC(n);
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = i == j;
-    double mv = 0;
-    int m;
-    for (int k = 0; k < n; k++) {
-        W[k] = A[(n + 1) * k];
-        if (k < n - 1) {
-            int i; for (m = k + 1, mv = std::abs(A[n * k + m]), i = k + 2; i < n; i++) { double v = std::abs(A[n * k + i]); if (mv < v) mv = v, m = i; }
-            indR[k] = m;
-        }
-        if (k > 0) {
-            int i; for (m = 0, mv = std::abs(A[k]), i = 1; i < k; i++) { double v = std::abs(A[n * i + k]); if (mv < v) mv = v, m = i; }
-            indC[k] = m;
-        }
-    }
-    if (n > 1) for (int iters = 0, maxIters = n * n * 30; iters < maxIters; iters++) {
-        int k, i;
-        for (k = 0, mv = std::abs(A[indR[0]]), i = 1; i < n - 1; i++) { double v = std::abs(A[n * i + indR[i]]); if (mv < v) mv = v, k = i; }
-        int l = indR[k];
-        for (i = 1; i < n; i++) { double v = std::abs(A[n * indC[i] + i]); if (mv < v) mv = v, k = indC[i], l = i; }
-        double p = A[n * k + l];
-        if (std::abs(p) <= eps) break;
-        double y = (W[l] - W[k]) * 0.5;
-        double t = std::abs(y) + std::hypot(p, y);
-        double s = std::hypot(p, t);
-        double c = t / s;
-        s = p / s; t = (p / t) * p;
-        if (y < 0) s = -s, t = -t;
-        A[n * k + l] = 0;
-        W[k] -= t; W[l] += t;
-        double a0, b0;
-#define ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
-        for (i = 0; i < k; i++) ROT(A[n * i + k], A[n * i + l]);
-        for (i = k + 1; i < l; i++) ROT(A[n * k + i], A[n * i + l]);
-        for (i = l + 1; i < n; i++) ROT(A[n * k + i], A[n * l + i]);
-        for (i = 0; i < n; i++) ROT(V[n * k + i], V[n * l + i]);
-#undef ROT
-        for (int j = 0; j < 2; j++) {
-            int idx = j == 0 ? k : l;
-            if (idx < n - 1) {
-                for (m = idx + 1, mv = std::abs(A[n * idx + m]), i = idx + 2; i < n; i++) { double v = std::abs(A[n * idx + i]); if (mv < v) mv = v, m = i; }
-                indR[idx] = m;
-            }
-            if (idx > 0) {
-                for (m = 0, mv = std::abs(A[idx]), i = 1; i < idx; i++) { double v = std::abs(A[n * i + idx]); if (mv < v) mv = v, m = i; }
-                indC[idx] = m;
-            }
-        }
-    }
-    for (int k = 0; k < n - 1; k++) {
-        m = k;
-        for (int i = k + 1; i < n; i++) if (W[m] < W[i]) m = i;
-        if (k != m) { std::swap(W[m], W[k]); for (int i = 0; i < n; i++) std::swap(V[n * m + i], V[n * k + i]); }
-    }
+HgWorkspace* hg_workspace_create() { return new HgWorkspace(); }
+void hg_workspace_destroy(HgWorkspace* w) {
+    if (!w) return;
+    for (DevBuf* b : {&w->pts, &w->frames, &w->samples, &w->scores, &w->err, &w->jobs, &w->results, &w->masks}) b->release();
+    if (w->pinned) (void)hipHostFree(w->pinned);
+    delete w;
 }
 
-// cv::solve / cv::invert with DECOMP_EIG on a symmetric n x n system (SVBkSb with the eigenvectors)
-void eig_solve(const double* A, int n, const double* b, int nb, double* x) {
-    std::vector<double> a(A, A + n * n), w(n), v(n * n);
-    jacobi(a.data(), n, w.data(), v.data());
-    double thr = 0;
-    for (int i = 0; i < n; i++) thr += w[i];
-    thr *= DBL_EPSILON * 2;
-    for (int i = 0; i < n * nb; i++) x[i] = 0;
-    for (int i = 0; i < n; i++) {
-        if (std::abs(w[i]) <= thr) continue;
-        const double wi = 1.0 / w[i];
-        for (int j = 0; j < nb; j++) {
-            double s = 0;
-            for (int k = 0; k < n; k++) s += v[i * n + k] * b[k * nb + j];
-            s *= wi;
-            for (int k = 0; k < n; k++) x[k * nb + j] += s * v[i * n + k];
-        }
-    }
-}
+namespace {
 
-struct P2 { float x, y; };
-
-// HomographyEstimatorCallback::runKernel — normalised DLT; M -> m. Returns false when degenerate.
-bool dlt(const P2* M, const P2* m, int count, double* H) {
-    double LtL[81], W[9], V[81];
-    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
-    for (int i = 0; i < count; i++) { cmx += m[i].x; cmy += m[i].y; cMx += M[i].x; cMy += M[i].y; }
-    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
-    for (int i = 0; i < count; i++) {
-        smx += std::fabs(m[i].x - cmx); smy += std::fabs(m[i].y - cmy);
-        sMx += std::fabs(M[i].x - cMx); sMy += std::fabs(M[i].y - cMy);
+// cv::RNG: 64-bit multiply-with-carry state, 32-bit outputs; uniform(a, b) = a + next() % (b - a)
+class MwcStream {
+public:
+    MwcStream() : s_(0xffffffffffffffffull) {}               // RNG(-1), the seed both registrators use
+    int below(int n) {
+        s_ = (uint64_t)(uint32_t)s_ * 4164903690u + (uint32_t)(s_ >> 32);
+        return (int)((uint32_t)s_ % (uint32_t)n);
     }
-    if (std::fabs(smx) < DBL_EPSILON || std::fabs(smy) < DBL_EPSILON || std::fabs(sMx) < DBL_EPSILON || std::fabs(sMy) < DBL_EPSILON) return false;
-    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
-    const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
-    const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
-    for (int i = 0; i < 81; i++) LtL[i] = 0;
-    for (int i = 0; i < count; i++) {
-        const double x = (m[i].x - cmx) * smx, y = (m[i].y - cmy) * smy;
-        const double X = (M[i].x - cMx) * sMx, Y = (M[i].y - cMy) * sMy;
-        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-        for (int j = 0; j < 9; j++) for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
-    }
-    for (int j = 0; j < 9; j++) for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
-    jacobi(LtL, 9, W, V);
-    const double* H0 = V + 72;                       // eigenvector of the smallest eigenvalue
-    double T[9], R[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += invHnorm[i * 3 + k] * H0[k * 3 + j]; T[i * 3 + j] = s; }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += T[i * 3 + k] * Hnorm2[k * 3 + j]; R[i * 3 + j] = s; }
-    const double sc = 1. / R[8];
-    for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
-    return true;
-}
+private:
+    uint64_t s_;
+};
 
-bool collinear(const P2* p, int count) {
-    const int i = count - 1;
-    for (int j = 0; j < i; j++) {
-        const double dx1 = p[j].x - p[i].x, dy1 = p[j].y - p[i].y;
+// Is the last of the 4 points (nearly) on a line through two of the others? (haveCollinearPoints: only triples that
+// contain the newest point are looked at.)
+bool newest_point_collinear(const float* xy /* 4 x 2 */) {
+    const double px = xy[6], py = xy[7];
+    for (int j = 0; j < 3; j++) {
+        const double ax = xy[2 * j] - px, ay = xy[2 * j + 1] - py;
         for (int k = 0; k < j; k++) {
-            const double dx2 = p[k].x - p[i].x, dy2 = p[k].y - p[i].y;
-            if (std::fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2))) return true;
+            const double bx = xy[2 * k] - px, by = xy[2 * k + 1] - py;
+            if (std::fabs(bx * ay - by * ax) <= FLT_EPSILON * (std::fabs(ax) + std::fabs(ay) + std::fabs(bx) + std::fabs(by))) return true;
         }
     }
     return false;
 }
-double det3(const P2& a, const P2& b, const P2& c) {
-    const double a00 = a.x, a01 = a.y, a10 = b.x, a11 = b.y, a20 = c.x, a21 = c.y;
-    return a00 * (a11 * 1. - 1. * a21) - a01 * (a10 * 1. - 1. * a20) + 1. * (a10 * a21 - a11 * a20);
+// determinant of [p q r] with a third coordinate of 1, expanded along the first row like cv::determinant on a Matx33d
+double orientation(const float* p, const float* q, const float* r) {
+    const double a = p[0], b = p[1], c = q[0], d = q[1], e = r[0], f = r[1];
+    return a * (d * 1. - 1. * f) - b * (c * 1. - 1. * e) + 1. * (c * f - d * e);
 }
-bool check_subset(const P2* s, const P2* d, int count) {
-    if (collinear(s, count) || collinear(d, count)) return false;
-    if (count == 4) {
-        static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
-        int negative = 0;
+// A sample is admissible when neither point set has its newest point on a line with two others and the four
+// point triples keep (or all flip) their orientation under the mapping.
+bool sample_admissible(const float* from4, const float* to4) {
+    if (newest_point_collinear(from4) || newest_point_collinear(to4)) return false;
+    static const int tri[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int flipped = 0;
+    for (const auto& t : tri)
+        flipped += orientation(from4 + 2 * t[0], from4 + 2 * t[1], from4 + 2 * t[2]) *
+                   orientation(to4 + 2 * t[0], to4 + 2 * t[1], to4 + 2 * t[2]) < 0;
+    return flipped == 0 || flipped == 4;
+}
+
+// RANSACUpdateNumIters(confidence p, outlier ratio ep, 4 model points, current cap)
+int iterations_needed(double p, double ep, int cap) {
+    p = std::min(std::max(p, 0.), 1.);
+    ep = std::min(std::max(ep, 0.), 1.);
+    const double miss = std::max(1. - p, DBL_MIN);
+    const double all_in = 1. - std::pow(1. - ep, 4);
+    if (all_in < DBL_MIN) return 0;
+    const double ln_miss = std::log(miss), ln_bad = std::log(all_in);
+    return ln_bad >= 0 || -ln_miss >= cap * (-ln_bad) ? cap : (int)std::lrint(ln_miss / ln_bad);
+}
+
+struct Track {                       // the sequential state of one robust estimation
+    int problem = -1;                // index into probs / out
+    int n = 0, pt_ofs = 0;
+    MwcStream rng;
+    std::vector<HgSample> samples;   // every sample drawn so far, in iteration order
+    bool stream_ended = false;       // no admissible sample within 1000 attempts: the loop ends there
+    int replayed = 0;                // iterations whose score has been consumed
+    int limit = 2000;                // RANSAC: current niters; LMEDS: fixed count
+    int best = -1, best_count = 0;   // RANSAC
+    double best_median = DBL_MAX;    // LMEDS
+    bool finished = false;
+    int round_first = 0, round_count = 0, hyp_ofs = 0, err_ofs = 0;
+};
+
+// draw the next sample of `t` (getSubset); false when 1000 attempts gave nothing admissible
+bool draw_sample(Track& t, const HgProblem& pr, HgSample& s) {
+    float from4[8], to4[8];
+    for (int attempt = 0; attempt < 1000; attempt++) {
         for (int i = 0; i < 4; i++) {
-            const int* t = tt[i];
-            negative += det3(s[t[0]], s[t[1]], s[t[2]]) * det3(d[t[0]], d[t[1]], d[t[2]]) < 0;
-        }
-        if (negative != 0 && negative != 4) return false;
-    }
-    return true;
-}
-
-int find_inliers(const P2* M, const P2* m, int count, const double* H, double thresh, uint8_t* mask) {
-    const float Hf[8] = {(float)H[0], (float)H[1], (float)H[2], (float)H[3], (float)H[4], (float)H[5], (float)H[6], (float)H[7]};
-    const float t = (float)(thresh * thresh);
-    int nz = 0;
-    for (int i = 0; i < count; i++) {
-        const float ww = 1.f / (Hf[6] * M[i].x + Hf[7] * M[i].y + 1.f);
-        const float dx = (Hf[0] * M[i].x + Hf[1] * M[i].y + Hf[2]) * ww - m[i].x;
-        const float dy = (Hf[3] * M[i].x + Hf[4] * M[i].y + Hf[5]) * ww - m[i].y;
-        const float e = dx * dx + dy * dy;
-        const int f = e <= t;
-        mask[i] = (uint8_t)f; nz += f;
-    }
-    return nz;
-}
-
-// HomographyEstimatorCallback::computeError: squared reprojection error in f32
-void reproj_errors(const P2* M, const P2* m, int count, const double* H, float* err) {
-    const float Hf[8] = {(float)H[0], (float)H[1], (float)H[2], (float)H[3], (float)H[4], (float)H[5], (float)H[6], (float)H[7]};
-    for (int i = 0; i < count; i++) {
-        const float ww = 1.f / (Hf[6] * M[i].x + Hf[7] * M[i].y + 1.f);
-        const float dx = (Hf[0] * M[i].x + Hf[1] * M[i].y + Hf[2]) * ww - m[i].x;
-        const float dy = (Hf[3] * M[i].x + Hf[4] * M[i].y + Hf[5]) * ww - m[i].y;
-        err[i] = dx * dx + dy * dy;
-    }
-}
-
-int ransac_update_iters(double p, double ep, int modelPoints, int maxIters) {
-    p = std::max(p, 0.); p = std::min(p, 1.);
-    ep = std::max(ep, 0.); ep = std::min(ep, 1.);
-    double num = std::max(1. - p, DBL_MIN);
-    double denom = 1. - std::pow(1. - ep, modelPoints);
-    if (denom < DBL_MIN) return 0;
-    num = std::log(num); denom = std::log(denom);
-    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : cv_round(num / denom);
-}
-
-// HomographyRefineCallback::compute
-void refine_compute(const P2* M, const P2* m, int count, const double* h, double* err, double* J) {
-    for (int i = 0; i < count; i++) {
-        const double Mx = M[i].x, My = M[i].y;
-        double ww = h[6] * Mx + h[7] * My + 1.;
-        ww = std::fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
-        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
-        const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
-        err[i * 2] = xi - m[i].x; err[i * 2 + 1] = yi - m[i].y;
-        if (J) {
-            double* j = J + (size_t)i * 16;
-            j[0] = Mx * ww; j[1] = My * ww; j[2] = ww; j[3] = j[4] = j[5] = 0.; j[6] = -Mx * ww * xi; j[7] = -My * ww * xi;
-            j[8] = j[9] = j[10] = 0.; j[11] = Mx * ww; j[12] = My * ww; j[13] = ww; j[14] = -Mx * ww * yi; j[15] = -My * ww * yi;
-        }
-    }
-}
-
-// LMSolverImpl::run (calib3d/src/levmarq.cpp), 8 parameters, maxIters 10, eps FLT_EPSILON
-void lm_refine(const P2* M, const P2* m, int count, double* H) {
-    const int lx = 8, maxIters = 10;
-    const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
-    std::vector<double> x(H, H + 8), xd(8), r(count * 2), rd(count * 2), J((size_t)count * 16), A(64), Ap(64), v(8), d(8), D(8), tmp(8);
-    auto normal = [&]() {
-        for (int a = 0; a < 8; a++) {
-            for (int b = 0; b < 8; b++) { double s = 0; for (int i = 0; i < count * 2; i++) s += J[(size_t)i * 8 + a] * J[(size_t)i * 8 + b]; A[a * 8 + b] = s; }
-            double s = 0; for (int i = 0; i < count * 2; i++) s += J[(size_t)i * 8 + a] * r[i]; v[a] = s;
-        }
-    };
-    auto sq = [](const std::vector<double>& q) { double s = 0; for (double e : q) s += e * e; return s; };
-    refine_compute(M, m, count, x.data(), r.data(), J.data());
-    double S = sq(r);
-    normal();
-    for (int i = 0; i < 8; i++) D[i] = A[i * 8 + i];
-    const double Rlo = 0.25, Rhi = 0.75;
-    double lambda = 1, lc = 0.75;
-    int iter = 0;
-    for (;;) {
-        Ap = A;
-        for (int i = 0; i < lx; i++) Ap[i * 8 + i] += lambda * D[i];
-        eig_solve(Ap.data(), 8, v.data(), 1, d.data());
-        for (int i = 0; i < 8; i++) xd[i] = x[i] - d[i];
-        refine_compute(M, m, count, xd.data(), rd.data(), nullptr);
-        const double Sd = sq(rd);
-        for (int i = 0; i < 8; i++) { double s = 0; for (int k = 0; k < 8; k++) s += A[i * 8 + k] * d[k]; tmp[i] = -s + 2 * v[i]; }
-        double dS = 0; for (int i = 0; i < 8; i++) dS += d[i] * tmp[i];
-        const double R = (S - Sd) / (std::fabs(dS) > DBL_EPSILON ? dS : 1);
-        if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
-        else if (R < Rlo) {
-            double t = 0; for (int i = 0; i < 8; i++) t += d[i] * v[i];
-            double nu = (Sd - S) / (std::fabs(t) > DBL_EPSILON ? t : 1) + 2;
-            nu = std::min(std::max(nu, 2.), 10.);
-            if (lambda == 0) {
-                double I8[64]; for (int i = 0; i < 64; i++) I8[i] = (i % 9 == 0);
-                std::vector<double> inv(64);
-                eig_solve(A.data(), 8, I8, 8, inv.data());
-                double maxval = DBL_EPSILON;
-                for (int i = 0; i < lx; i++) maxval = std::max(maxval, std::abs(inv[i * 8 + i]));
-                lambda = lc = 1. / maxval;
-                nu *= 0.5;
+            int pick = t.rng.below(t.n);
+            for (;;) {
+                bool repeated = false;
+                for (int k = 0; k < i; k++) repeated |= s.idx[k] == pick;
+                if (!repeated) break;
+                pick = t.rng.below(t.n);
             }
-            lambda *= nu;
+            s.idx[i] = pick;
+            from4[2 * i] = pr.from_pts[2 * pick]; from4[2 * i + 1] = pr.from_pts[2 * pick + 1];
+            to4[2 * i] = pr.to_pts[2 * pick]; to4[2 * i + 1] = pr.to_pts[2 * pick + 1];
         }
-        if (Sd < S) {
-            S = Sd;
-            std::swap(x, xd);
-            refine_compute(M, m, count, x.data(), r.data(), J.data());
-            normal();
-        }
-        iter++;
-        double nd = 0, nr = 0;
-        for (int i = 0; i < 8; i++) nd = std::max(nd, std::fabs(d[i]));
-        for (double e : r) nr = std::max(nr, std::fabs(e));
-        const bool proceed = iter < maxIters && nd >= epsx && nr >= epsf;
-        if (!proceed) break;
+        if (sample_admissible(from4, to4)) return true;
     }
-    for (int i = 0; i < 8; i++) H[i] = x[i];
+    return false;
 }
 
+hipError_t ensure_pinned(HgWorkspace* ws, size_t bytes) {
+    if (bytes <= ws->pinned_cap) return hipSuccess;
+    if (ws->pinned) (void)hipHostFree(ws->pinned);
+    ws->pinned = nullptr; ws->pinned_cap = 0;
+    const size_t want = bytes + (bytes >> 2) + 4096;
+    hipError_t e = hipHostMalloc(&ws->pinned, want, hipHostMallocDefault);
+    if (e == hipSuccess) ws->pinned_cap = want;
+    return e;
+}
 
-// Returns 0 with *found (1: H valid, 0: OpenCV would return an empty Mat); 3 = arguments OpenCV rejects
-// with an exception (fewer than 4 points, unknown method); 7 = method not implemented (LMEDS, RHO).
-int find_homography(const float* src_pts, const float* dst_pts, int n, int method, double thr, double* H,
-                    uint8_t* mask_out, int* found) {
-    *found = 0;
-    if (n < 4) return 3;
-    if (method != 0 && method != 8 && method != 4) return method == 16 ? 7 : 3;
-    if (thr <= 0) thr = 3;
-    std::vector<P2> src(n), dst(n);
-    for (int i = 0; i < n; i++) { src[i] = {src_pts[2 * i], src_pts[2 * i + 1]}; dst[i] = {dst_pts[2 * i], dst_pts[2 * i + 1]}; }
-    std::vector<uint8_t> mask(n, 1);
-    bool result = false;
-    if (method == 0 || n == 4) {
-        result = dlt(src.data(), dst.data(), n, H);
-    } else if (method == 4) {
-        // LMeDSPointSetRegistrator::run (calib3d/src/ptsetreg.cpp): fixed iteration count from an assumed
-        // 45% outlier ratio, model with the least median squared reprojection error, inliers from the robust sigma
-        const int modelPoints = 4;
-        const int niters = ransac_update_iters(0.995, 0.45, modelPoints, 2000);
-        Rng rng((uint64_t)-1);
-        std::vector<float> err(n);
-        double model[9], bestModel[9], minMedian = DBL_MAX;
-        P2 ms1[4], ms2[4];
-        for (int iter = 0; iter < niters; iter++) {
-            bool got = false;
-            for (int attempt = 0; attempt < 1000 && !got; attempt++) {
-                int idx[4];
-                for (int i = 0; i < modelPoints; i++) {
-                    int idx_i;
-                    for (idx_i = rng.uniform(0, n); std::find(idx, idx + i, idx_i) != idx + i; idx_i = rng.uniform(0, n)) {}
-                    idx[i] = idx_i;
-                    ms1[i] = src[idx_i]; ms2[i] = dst[idx_i];
+}  // namespace
+
+int find_homography_batch(stk_ctx* ctx, hipStream_t stream, HgWorkspace* ws, const HgProblem* probs, int count, int method,
+                          double thr, HgOutcome* out) {
+    if (count <= 0) return STK_OK;
+    if (thr <= 0) thr = 3;           // findHomography: ransacReprojThreshold <= 0 -> default 3
+    const bool ransac = method == 8, lmeds = method == 4;
+    // ---- admission + point packing --------------------------------------------------------------------------------
+    std::vector<int> live;           // problems that reach the device
+    size_t n_points = 0;
+    for (int i = 0; i < count; i++) {
+        out[i] = HgOutcome{};
+        if (probs[i].n < 4 || (method != 0 && !ransac && !lmeds)) {
+            out[i].rc = probs[i].n >= 4 && method == 16 ? 7 : 3;
+            if (probs[i].mask_or_null && probs[i].n > 0) std::memset(probs[i].mask_or_null, 0, probs[i].n);
+            continue;
+        }
+        if (probs[i].n > HG_MAX_POINTS) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: more than 4096 correspondences");
+        live.push_back(i);
+        n_points += (size_t)probs[i].n;
+    }
+    if (live.empty()) return STK_OK;
+    const int L = (int)live.size();
+    HIP_TRY(ws->pts.reserve(n_points * sizeof(HgPoint)));
+    HIP_TRY(ws->masks.reserve(n_points));
+    HIP_TRY(ws->jobs.reserve(sizeof(HgJob) * L));
+    HIP_TRY(ws->results.reserve(sizeof(HgResult) * L));
+    HIP_TRY(ws->frames.reserve(sizeof(HgFrame) * L));
+    const size_t stage_fixed = n_points * sizeof(HgPoint) + n_points + (sizeof(HgJob) + sizeof(HgResult) + sizeof(HgFrame)) * (size_t)L;
+    HIP_TRY(ensure_pinned(ws, stage_fixed + 64));
+    std::vector<Track> tracks(L);
+    {
+        HgPoint* hp = (HgPoint*)ws->pinned;
+        size_t ofs = 0;
+        for (int k = 0; k < L; k++) {
+            const HgProblem& pr = probs[live[k]];
+            Track& t = tracks[k];
+            t.problem = live[k]; t.n = pr.n; t.pt_ofs = (int)ofs;
+            for (int i = 0; i < pr.n; i++) hp[ofs + i] = HgPoint{pr.from_pts[2 * i], pr.from_pts[2 * i + 1], pr.to_pts[2 * i], pr.to_pts[2 * i + 1]};
+            ofs += (size_t)pr.n;
+        }
+        HIP_TRY(hipMemcpyAsync(ws->pts.p, hp, n_points * sizeof(HgPoint), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));        // the staging area is reused below
+    }
+
+    // ---- robust stage: rounds of speculative model evaluation -------------------------------------------------------
+    std::vector<HgJob> jobs(L);
+    for (int k = 0; k < L; k++) {
+        Track& t = tracks[k];
+        jobs[k] = HgJob{t.pt_ofs, t.n, {0, 0, 0, 0}, 0.f, 0};
+        if (method == 0 || t.n == 4) { t.finished = true; continue; }       // plain DLT (+ LM when n > 4)
+        t.limit = lmeds ? iterations_needed(0.995, 0.45, 2000) : 2000;      // LMEDS: fixed, from an assumed 45 % of outliers
+    }
+    const float thr2 = (float)(thr * thr);
+    for (int round = 0;; round++) {
+        const int round_cap = round == 0 ? 32 : round == 1 ? 256 : 2000;
+        // draw this round's samples
+        int n_active = 0, hyp_total = 0, max_hyp = 0;
+        size_t err_total = 0;
+        for (Track& t : tracks) {
+            t.round_count = 0;
+            if (t.finished) continue;
+            const HgProblem& pr = probs[t.problem];
+            t.round_first = (int)t.samples.size();
+            const int want = std::min(lmeds ? t.limit : round_cap, t.limit - t.round_first);
+            for (int k = 0; k < want && !t.stream_ended; k++) {
+                HgSample s{};
+                if (draw_sample(t, pr, s)) t.samples.push_back(s);
+                else t.stream_ended = true;
+            }
+            t.round_count = (int)t.samples.size() - t.round_first;
+            if (t.round_count == 0) { t.finished = true; continue; }        // the sample stream ended: loop over
+            t.hyp_ofs = hyp_total; t.err_ofs = (int)err_total;
+            hyp_total += t.round_count;
+            max_hyp = std::max(max_hyp, t.round_count);
+            if (lmeds) err_total += (size_t)t.round_count * t.n;
+            n_active++;
+        }
+        if (n_active == 0) break;
+        if (err_total > (size_t)1 << 30) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography(LMEDS): batch too large");
+        // upload frames + samples, evaluate, fetch scores
+        HIP_TRY(ws->samples.reserve(sizeof(HgSample) * (size_t)hyp_total));
+        HIP_TRY(ws->scores.reserve(sizeof(int) * (size_t)hyp_total));
+        if (lmeds) HIP_TRY(ws->err.reserve(sizeof(float) * err_total));
+        const size_t stage = (sizeof(HgSample) + sizeof(int)) * (size_t)hyp_total + sizeof(HgFrame) * (size_t)n_active;
+        HIP_TRY(ensure_pinned(ws, std::max(stage, stage_fixed) + 64));
+        HgSample* hs = (HgSample*)ws->pinned;
+        int* hscore = (int*)(hs + hyp_total);
+        HgFrame* hf = (HgFrame*)(hscore + hyp_total);
+        int fi = 0;
+        for (Track& t : tracks) {
+            if (t.finished || t.round_count == 0) continue;
+            std::memcpy(hs + t.hyp_ofs, t.samples.data() + t.round_first, sizeof(HgSample) * (size_t)t.round_count);
+            hf[fi++] = HgFrame{t.pt_ofs, t.n, t.hyp_ofs, t.round_count, t.err_ofs, thr2};
+        }
+        HIP_TRY(hipMemcpyAsync(ws->samples.p, hs, sizeof(HgSample) * (size_t)hyp_total, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(ws->frames.p, hf, sizeof(HgFrame) * (size_t)n_active, hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_hg_models(ws->pts.as<HgPoint>(), ws->frames.as<HgFrame>(), n_active, max_hyp, ws->samples.as<HgSample>(),
+                                 lmeds ? 1 : 0, ws->err.as<float>(), ws->scores.as<int>(), stream));
+        HIP_TRY(hipMemcpyAsync(hscore, ws->scores.p, sizeof(int) * (size_t)hyp_total, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        // replay the sequential decisions
+        for (Track& t : tracks) {
+            if (t.finished || t.round_count == 0) continue;
+            const int* sc = hscore + t.hyp_ofs;
+            int it = t.round_first;
+            const int end = t.round_first + t.round_count;
+            for (; it < end && it < t.limit; it++) {
+                const int s = sc[it - t.round_first];
+                if (lmeds) {
+                    float med; std::memcpy(&med, &s, 4);
+                    if (s != -1 && (double)med < t.best_median) { t.best_median = med; t.best = it; }
+                } else if (s > std::max(t.best_count, 3)) {                 // `good > max(maxGoodCount, modelPoints - 1)`
+                    t.best = it; t.best_count = s;
+                    t.limit = iterations_needed(0.995, (double)(t.n - s) / t.n, t.limit);
                 }
-                got = check_subset(ms1, ms2, modelPoints);
             }
-            if (!got) { if (iter == 0) { return 0; } break; }
-            if (!dlt(ms1, ms2, modelPoints, model)) continue;
-            reproj_errors(src.data(), dst.data(), n, model, err.data());
-            std::nth_element(err.begin(), err.begin() + n / 2, err.end());
-            const double median = err[n / 2];
-            if (median < minMedian) { minMedian = median; std::memcpy(bestModel, model, sizeof(model)); }
+            t.replayed = it;
+            out[t.problem].models_evaluated = end;
+            if (it >= t.limit || t.stream_ended) t.finished = true;
         }
-        if (minMedian < DBL_MAX) {
-            double sigma = 2.5 * 1.4826 * (1 + 5. / (n - modelPoints)) * std::sqrt(minMedian);
+    }
+    // ---- jobs for the refinement launch ---------------------------------------------------------------------------------
+    for (int k = 0; k < L; k++) {
+        Track& t = tracks[k];
+        HgJob& j = jobs[k];
+        if (method == 0 || t.n == 4) { j.mode = 0; continue; }
+        if (t.best < 0) { j.mode = -1; continue; }                           // no admissible sample / no model with > 3 inliers
+        j.mode = 1;
+        for (int q = 0; q < 4; q++) j.idx[q] = t.samples[t.best].idx[q];
+        if (lmeds) {
+            // sigma = 2.5 * 1.4826 * (1 + 5 / (n - 4)) * sqrt(min median), at least 0.001; inliers: err <= sigma^2 (f32)
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (t.n - 4)) * std::sqrt(t.best_median);
             sigma = std::max(sigma, 0.001);
-            const int good = find_inliers(src.data(), dst.data(), n, bestModel, sigma, mask.data());
-            std::memcpy(H, bestModel, sizeof(bestModel));
-            result = good >= modelPoints;
-        }
-    } else {
-        const int modelPoints = 4;
-        const double confidence = 0.995;
-        int niters = 2000, maxGood = 0;
-        Rng rng((uint64_t)-1);
-        std::vector<uint8_t> cur(n), best(n, 0);
-        double model[9], bestModel[9];
-        P2 ms1[4], ms2[4];
-        for (int iter = 0; iter < niters; iter++) {
-            bool got = false;
-            for (int attempt = 0; attempt < 1000 && !got; attempt++) {
-                int idx[4];
-                for (int i = 0; i < modelPoints; i++) {
-                    int idx_i;
-                    for (idx_i = rng.uniform(0, n); std::find(idx, idx + i, idx_i) != idx + i; idx_i = rng.uniform(0, n)) {}
-                    idx[i] = idx_i;
-                    ms1[i] = src[idx_i]; ms2[i] = dst[idx_i];
-                }
-                got = check_subset(ms1, ms2, modelPoints);
-            }
-            if (!got) { if (iter == 0) { return 0; } break; }
-            if (!dlt(ms1, ms2, modelPoints, model)) continue;
-            const int good = find_inliers(src.data(), dst.data(), n, model, thr, cur.data());
-            if (good > std::max(maxGood, modelPoints - 1)) {
-                std::swap(cur, best);
-                std::memcpy(bestModel, model, sizeof(model));
-                maxGood = good;
-                niters = ransac_update_iters(confidence, (double)(n - good) / n, modelPoints, niters);
-            }
-        }
-        if (maxGood > 0) { std::memcpy(H, bestModel, sizeof(bestModel)); mask = best; result = true; }
+            j.thr2 = (float)(sigma * sigma);
+        } else j.thr2 = thr2;
     }
-    if (result && n > 4) {
-        std::vector<P2> s2, d2;
-        for (int i = 0; i < n; i++) if (mask[i]) { s2.push_back(src[i]); d2.push_back(dst[i]); }
-        const int np = (int)s2.size();
-        if (np > 0) {
-            if (method == 8 || method == 4) dlt(s2.data(), d2.data(), np, H);
-            lm_refine(s2.data(), d2.data(), np, H);
-        }
+    HIP_TRY(ensure_pinned(ws, stage_fixed + 64));
+    HgJob* hj = (HgJob*)ws->pinned;
+    HgResult* hr = (HgResult*)(hj + L);
+    uint8_t* hm = (uint8_t*)(hr + L);
+    std::memcpy(hj, jobs.data(), sizeof(HgJob) * L);
+    HIP_TRY(hipMemcpyAsync(ws->jobs.p, hj, sizeof(HgJob) * L, hipMemcpyHostToDevice, stream));
+    HIP_TRY(launch_hg_refine(ws->pts.as<HgPoint>(), ws->jobs.as<HgJob>(), L, ws->results.as<HgResult>(), ws->masks.as<uint8_t>(), stream));
+    HIP_TRY(hipMemcpyAsync(hr, ws->results.p, sizeof(HgResult) * L, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(hm, ws->masks.p, n_points, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < L; k++) {
+        const Track& t = tracks[k];
+        HgOutcome& o = out[t.problem];
+        o.found = hr[k].found;
+        o.n_inliers = hr[k].found ? hr[k].n_inliers : 0;
+        for (int q = 0; q < 9; q++) o.H[q] = hr[k].H[q];
+        if (probs[t.problem].mask_or_null) std::memcpy(probs[t.problem].mask_or_null, hm + t.pt_ofs, (size_t)t.n);
     }
-    if (result) { *found = 1; if (mask_out) std::memcpy(mask_out, mask.data(), n); }
-    else if (mask_out) std::memset(mask_out, 0, n);
-    return 0;
+    return STK_OK;
 }
-
 
 }  // namespace geom
 }  // namespace stk

@@ -15,11 +15,13 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
 #include "context.h"
 #include "homography.h"
+#include "host_pool.h"
 #include "orb_pattern.h"
 
 using namespace stk;
@@ -130,64 +132,6 @@ constexpr int ORB_PACK = 512;     // short-list entries per level fetched in the
 }  // namespace
 
 namespace stk {
-
-// A small persistent pool for the per-frame host steps (spawning 12 threads twice per stack cost ~0.5 ms of a 6 ms stack).
-class HostPool {
-public:
-    explicit HostPool(int n) {
-        for (int i = 0; i < n; i++) workers_.emplace_back([this]() { loop(); });
-    }
-    ~HostPool() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
-    int size() const { return (int)workers_.size(); }
-    // run fn(i) for i in [0, n); the calling thread takes part; returns when all are done
-    void run(int n, const std::function<void(int)>& fn) {
-        if (n <= 0) return;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn; n_ = n; next_.store(0); pending_ = n; gen_++;
-        }
-        cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this]() { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-private:
-    void work() {
-        for (;;) {
-            const int i = next_.fetch_add(1);
-            if (i >= n_) break;
-            (*fn_)(i);
-            std::lock_guard<std::mutex> lk(m_);
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    void loop() {
-        unsigned long long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
-            }
-            work();
-        }
-    }
-    std::vector<std::thread> workers_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int)>* fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_ = 0, pending_ = 0;
-    unsigned long long gen_ = 0;
-    bool stop_ = false;
-};
 
 void host_pool_destroy(HostPool* p) { delete p; }
 
@@ -412,11 +356,16 @@ stk_status stk_find_homography(stk_ctx* ctx, const float* src_pts, const float* 
                                double thr, double* H, uint8_t* inlier_mask, int32_t* found) {
     if (!ctx) return STK_INVALID_PARAMS;
     if (!src_pts || !dst_pts || !H || !found) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
-    int f = 0;
-    const int rc = geom::find_homography(src_pts, dst_pts, n, method, thr, H, inlier_mask, &f);
-    *found = f;
-    if (rc == 7) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: RHO is not implemented");
-    if (rc != 0) return fail(ctx, STK_BACKEND_ERROR, "findHomography: needs at least 4 point pairs and a known method");
+    (void)hipSetDevice(ctx->device);
+    *found = 0;
+    geom::HgProblem pr{src_pts, dst_pts, n, inlier_mask};
+    geom::HgOutcome o;
+    const int st = geom::find_homography_batch(ctx, ctx->stream, ctx->hg, &pr, 1, method, thr, &o);
+    if (st) return (stk_status)st;
+    if (o.rc == 7) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: RHO is not implemented");
+    if (o.rc != 0) return fail(ctx, STK_BACKEND_ERROR, "findHomography: needs at least 4 point pairs and a known method");
+    *found = o.found;
+    for (int k = 0; k < 9; k++) H[k] = o.H[k];
     return STK_OK;
 }
 
@@ -523,13 +472,13 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
             HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
+        // C2/C3 on host threads: Lowe ratio, stable sort, truncate, point gather (lib.rs:221-264)
+        std::vector<std::vector<float>> from_pts(n_mov), to_pts(n_mov);
         parallel_for(ctx, n_mov, threads, [&](int m) {
             const int i = b0 + first + m;
             const std::vector<HostKeypoint>& kp = kps[first + m];
             KpAlign& R = results[i];
             R.n_keypoints = (int)kp.size();
-            bool ok = true;
-            double* H = R.H;
             std::vector<Match> ms;
             if (n0 > 0) {
                 const int* knn = knn_host + (size_t)m * n0 * 4;
@@ -542,27 +491,39 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 const size_t keep = (size_t)std::round((float)ms.size() * params->match_keep_ratio);              // lib.rs:235
                 if (keep < ms.size()) ms.resize(keep);
             }
-            if (ms.size() < 5) ok = false;                                               // lib.rs:240
-            else {
-                std::vector<float> sp(ms.size() * 2), dp(ms.size() * 2);
-                std::vector<uint8_t> mask(ms.size());
-                for (size_t k = 0; k < ms.size(); k++) {
-                    sp[2 * k] = kp0[ms[k].q].x; sp[2 * k + 1] = kp0[ms[k].q].y;          // src_pts: frame 0  lib.rs:245-253
-                    dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;            // dst_pts: frame i  lib.rs:256-264
-                }
-                int found = 0;
-                const int rc = geom::find_homography(dp.data(), sp.data(), (int)ms.size(), params->method,
-                                                     params->ransac_reproj_threshold, H, mask.data(), &found);   // lib.rs:267
-                if (rc != 0 || !found) ok = false;                                       // Err(_) | empty -> skip  lib.rs:275-282
-                else {
-                    const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
-                    if (std::fabs(det) < 1e-6) ok = false;                               // lib.rs:284 / 521 (on the small-image H)
-                    else if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
-                    for (uint8_t mk : mask) R.n_inliers += mk;
-                }
+            R.n_matches = (int)ms.size();
+            if (ms.size() < 5) return;                                                   // lib.rs:240: dropped
+            std::vector<float>& dp = from_pts[m];                                        // find_homography(dst_pts, src_pts): frame i -> frame 0
+            std::vector<float>& sp = to_pts[m];
+            sp.resize(ms.size() * 2); dp.resize(ms.size() * 2);
+            for (size_t k = 0; k < ms.size(); k++) {
+                sp[2 * k] = kp0[ms[k].q].x; sp[2 * k + 1] = kp0[ms[k].q].y;              // src_pts: frame 0  lib.rs:245-253
+                dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;                // dst_pts: frame i  lib.rs:256-264
             }
-            R.ok = ok; R.n_matches = (int)ms.size();
         });
+        // D1 on the device for the whole batch (lib.rs:267-276), D2 checks on the host (lib.rs:279-287)
+        std::vector<geom::HgProblem> probs;
+        std::vector<int> owner;
+        for (int m = 0; m < n_mov; m++)
+            if (!from_pts[m].empty()) { probs.push_back({from_pts[m].data(), to_pts[m].data(), (int)from_pts[m].size() / 2, nullptr}); owner.push_back(m); }
+        std::vector<geom::HgOutcome> outc(probs.size());
+        if (!probs.empty()) {
+            const int hst = geom::find_homography_batch(ctx, s, ctx->hg, probs.data(), (int)probs.size(), params->method,
+                                                        params->ransac_reproj_threshold, outc.data());
+            if (hst) return (stk_status)hst;
+        }
+        for (size_t k = 0; k < probs.size(); k++) {
+            KpAlign& R = results[b0 + first + owner[k]];
+            const geom::HgOutcome& o = outc[k];
+            if (o.rc != 0 || !o.found) continue;                                         // Err(_) | empty -> skip  lib.rs:275-282
+            double* H = R.H;
+            for (int q = 0; q < 9; q++) H[q] = o.H[q];
+            const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
+            if (std::fabs(det) < 1e-6) continue;                                         // lib.rs:284 / 521 (on the small-image H)
+            if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
+            R.n_inliers = o.n_inliers;
+            R.ok = true;
+        }
     }
 
     if (n_ref_keypoints) *n_ref_keypoints = n0;

@@ -82,6 +82,7 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
     for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     if (hipHostMalloc((void**)&ctx->host_done, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     ctx->kp = keypoint_workspace_create();
+    ctx->hg = geom::hg_workspace_create();
     *out = ctx;
     return STK_OK;
 }
@@ -94,6 +95,7 @@ void stk_destroy(stk_ctx* ctx) {
                       &ctx->partials, &ctx->warpframes, &ctx->acc, &ctx->scratch, &ctx->init_warps})
         b->release();
     keypoint_workspace_destroy(ctx->kp);
+    geom::hg_workspace_destroy(ctx->hg);
     host_pool_destroy(ctx->host_pool);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);

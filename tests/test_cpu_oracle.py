@@ -235,3 +235,24 @@ def test_sharpness_known_answers():
     assert oracle.sharpness(dot, 1) == pytest.approx((4096 + 1024) / 25.0, rel=1e-15)
     with pytest.raises(ValueError):
         oracle.sharpness(flat, 2, 2)
+
+
+def test_homography_lm_floor():
+    """How well is findHomography's result defined at all? Re-ordering the correspondences changes nothing but the
+    order of the oracle's f64 sums, yet H moves by up to ~1.5e-8 relative: LMSolver accepts a step only when it lowers
+    the f64 cost, so the minimiser is resolved to ~sqrt(eps * S / curvature). This is the floor behind the 2e-7
+    tolerance of the GPU-vs-oracle comparisons (tests/test_gpu_homography.py, H_RTOL)."""
+    from libstacker_rs_amd import synth
+    rng = np.random.default_rng(2)
+    worst = 0.0
+    for _ in range(20):
+        n = int(rng.integers(50, 400))
+        src = rng.uniform(0, 1920, (n, 2)).astype(np.float32)
+        Hs = synth.random_homography(rng, 1920, 1080, strength=3.0)
+        p = np.c_[src.astype(np.float64), np.ones(n)] @ Hs.T
+        dst = (p[:, :2] / p[:, 2:] + rng.normal(0, 0.5, (n, 2))).astype(np.float32)
+        H1, _ = oracle.find_homography(src, dst, 0, 3.0)
+        perm = rng.permutation(n)
+        H2, _ = oracle.find_homography(src[perm], dst[perm], 0, 3.0)
+        worst = max(worst, float(np.max(np.abs(H1 - H2) / np.maximum(np.abs(H1), 1e-3))))
+    assert 1e-10 < worst < 2e-7, worst

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import oracle
+from conftest import assert_ecc_stack_close
 from libstacker_rs_amd import (EccMatchParameters, InvalidParams, KeyPointMatchParameters, MotionType, OpenCvError, RANSAC,
                                synth)
 
@@ -35,8 +36,8 @@ def test_hybrid_match_matches_oracle(stacker, bits):
         # other run to max_count while moving the corners by < 0.05 px); the warps are.
         assert stats[i]["iterations"] <= 200 and int(iters[i]) <= 200
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 0.3        # vs generator ground truth
-    rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
-    assert np.percentile(rel[4:-4, 4:-4], 99.5) < 3e-3
+    assert_ecc_stack_close(out, ref, fr, warps, alpha=1.0 / 65535.0 if bits == 16 else 1.0 / 255.0, label="hybrid %d-bit" % bits,
+                           iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
     assert 0.0 <= out.min() and out.max() <= 1.0 + 1e-6                           # alpha 1/65535 resp. 1/255: unit range
 
 

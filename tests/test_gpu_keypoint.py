@@ -3,10 +3,16 @@ import numpy as np
 import pytest
 
 import oracle
+from conftest import assert_stack_close
 from libstacker_rs_amd import (InvalidParams, KeyPointMatchParameters, NotEnoughFiles, NotImplementedYet, OpenCvError,
                                RANSAC, LMEDS, RHO, synth)
 
 pytestmark = pytest.mark.gpu
+
+# findHomography vs the oracle: inlier masks identical; H to 2e-7 relative. Not tighter because LMSolver accepts a step only
+# if it lowers the f64 cost S, which resolves the minimiser to ~sqrt(eps * S / curvature) ~ 2e-8 px in translation: the
+# oracle itself moves by 1.5e-8 when its points are merely re-ordered (tests/test_cpu_oracle.py::test_homography_lm_floor).
+H_RTOL = 2e-7
 
 PARAMS = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
 
@@ -72,7 +78,7 @@ def test_find_homography_known_answers(stacker):
     dst_o[::3] += rng.uniform(30, 80, dst_o[::3].shape).astype(np.float32)
     H, mask = stacker.find_homography(src, dst_o, RANSAC, 3.0)
     Ho, masko = oracle.find_homography(src, dst_o, 8, 3.0)
-    assert np.array_equal(mask, masko) and np.allclose(H, Ho, rtol=0, atol=1e-12)
+    assert np.array_equal(mask, masko) and np.allclose(H, Ho, rtol=H_RTOL, atol=1e-9)
     assert mask[::3].sum() == 0 and mask.sum() == len(src) - len(src[::3])
     assert synth.corner_error(H, Ht, 640, 480) < 0.05
     # least squares (method 0)
@@ -85,7 +91,7 @@ def test_find_homography_known_answers(stacker):
     # LMEDS: least median of squares, < 45% outliers by construction of the method
     Hl, maskl = stacker.find_homography(src, dst_o, LMEDS, 3.0)
     Hlo, masklo = oracle.find_homography(src, dst_o, 4, 3.0)
-    assert np.array_equal(maskl, masklo) and np.allclose(Hl, Hlo, rtol=0, atol=1e-12)
+    assert np.array_equal(maskl, masklo) and np.allclose(Hl, Hlo, rtol=H_RTOL, atol=1e-9)
     assert maskl[::3].sum() == 0 and synth.corner_error(Hl, Ht, 640, 480) < 0.05
     # collinear points: no model
     line = np.c_[np.arange(20), 2 * np.arange(20)].astype(np.float32)
@@ -109,11 +115,10 @@ def test_keypoint_match_stack_matches_oracle(stacker, kp_stack):
     d_o, ref, Hs, status = oracle.keypoint_match(list(frames), details=True)
     assert dropped == 0 and d_o == 0
     for i in range(1, len(frames)):
-        assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-10)      # same matches -> same RANSAC trace
+        assert np.allclose(stats[i]["warp"], Hs[i], rtol=H_RTOL, atol=1e-9)   # same matches -> same RANSAC decisions
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 1.0   # vs generator ground truth
         assert stats[i]["n_matches"] >= 100
-    assert np.max(np.abs(out - ref)) <= 4e-6                                   # <= 1e-6 per folded frame
-    assert np.max(np.abs(out - ref)) <= 1e-4 * np.max(np.abs(ref))            # north-star tolerance
+    assert_stack_close(out, ref)                                   # <= 1e-6 per folded frame
 
 
 def test_keypoint_match_drops_unmatchable_frame(stacker, kp_stack):
@@ -123,7 +128,7 @@ def test_keypoint_match_drops_unmatchable_frame(stacker, kp_stack):
     dropped, out, stats = stacker.keypoint_match(stack, PARAMS, return_stats=True)
     d_o, ref = oracle.keypoint_match(stack)
     assert dropped == 1 and d_o == 1 and stats[2]["status"] == 1
-    assert np.max(np.abs(out - ref)) <= 4e-6       # divisor is n - dropped = 3 (documented semantics, lib.rs:98)
+    assert_stack_close(out, ref)       # divisor is n - dropped = 3 (documented semantics, lib.rs:98)
     # the same stack without the bad frame gives the same image
     d2, out2 = stacker.keypoint_match([frames[0], frames[1], frames[2]], PARAMS)
     assert d2 == 0 and np.array_equal(out, out2)
@@ -154,11 +159,11 @@ def test_keypoint_match_border_mode_and_value(stacker, kp_stack):
     p = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9, oracle.BORDER_REPLICATE, (0, 0, 0, 0))
     _, out = stacker.keypoint_match(list(frames[:3]), p)
     _, ref = oracle.keypoint_match(list(frames[:3]), border_mode=oracle.BORDER_REPLICATE)
-    assert np.max(np.abs(out - ref)) <= 4e-6
+    assert_stack_close(out, ref)
     p = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9, oracle.BORDER_CONSTANT, (0.5, 0.25, 1.0, 0))
     _, out = stacker.keypoint_match(list(frames[:3]), p)
     _, ref = oracle.keypoint_match(list(frames[:3]), border_value=(0.5, 0.25, 1.0, 0))
-    assert np.max(np.abs(out - ref)) <= 4e-6
+    assert_stack_close(out, ref)
 
 
 def test_scale_image_inter_area_bit_exact(stacker):
@@ -180,9 +185,9 @@ def test_keypoint_match_scale_down_matches_oracle(stacker, kp_stack):
     d_o, ref, Hs, status = oracle.keypoint_match(list(frames), details=True, scale_down_width=300.0)
     assert dropped == d_o == 0
     for i in range(1, len(frames)):
-        assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-9)         # incl. the 4-entry rescale (utils.rs:236-239)
+        assert np.allclose(stats[i]["warp"], Hs[i], rtol=H_RTOL, atol=1e-9)         # incl. the 4-entry rescale (utils.rs:236-239)
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 2.5    # coarser: features found at 0.62x
-    assert np.max(np.abs(out - ref)) <= 4e-6
+    assert_stack_close(out, ref)
 
 
 def test_keypoint_match_lmeds_matches_oracle(stacker, kp_stack):
@@ -192,9 +197,9 @@ def test_keypoint_match_lmeds_matches_oracle(stacker, kp_stack):
     d_o, ref, Hs, status = oracle.keypoint_match(list(frames[:3]), method=4, details=True)
     assert dropped == d_o == 0
     for i in (1, 2):
-        assert np.allclose(stats[i]["warp"], Hs[i], rtol=0, atol=1e-10)
+        assert np.allclose(stats[i]["warp"], Hs[i], rtol=H_RTOL, atol=1e-9)
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 1.0
-    assert np.max(np.abs(out - ref)) <= 4e-6
+    assert_stack_close(out, ref)
     with pytest.raises(NotImplementedYet):
         stacker.keypoint_match(list(frames[:2]), KeyPointMatchParameters(RHO, 5.0, 0.80, 0.9))
 
