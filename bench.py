@@ -6,9 +6,11 @@ resident in HBM: ecc_match (grey -> blur -> ECC homography, 5000 iters / eps 1e-
 reference example's parameters, examples/main.rs:107-112) -> warpPerspective -> f32 accumulate,
 then the cross-rank reduce of the accumulator (RCCL) and the final 1/n scale on rank 0.
 
-Default workload = BASELINE.json configs[3] cut to one GPU: 3840x2160 BGR u8, 32 frames per GPU
-(256 frames over 8 GPUs). Frames are sharded contiguously, one process per GPU, no data-path
-collective except the single accumulator reduce ("scaling": "weak").
+Default workload = BASELINE.json configs[3]: ONE 256-frame 3840x2160 BGR u8 stack, the moving frames
+sharded contiguously over the N ranks (256/N frames per GPU; N = 8 gives the 32 per GPU configs[3] names;
+N = 1 holds all 256: 6.4 GB of frames + 8.5 GB of ECC templates). Total work is fixed: "scaling": "strong".
+One process per GPU, no data-path collective except the single accumulator reduce.
+--frames-per-gpu F runs F frames on every rank instead (weak scaling, for experiments).
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -30,13 +32,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 WORKLOADS = {
-    # name: (width, height, frames per GPU, api)
-    "ecc_4k": (3840, 2160, 32, "ecc"),
-    "ecc_1080p": (1920, 1080, 64, "ecc"),
-    "keypoint_1080p": (1920, 1080, 64, "keypoint"),
+    # name: (width, height, frames in the WHOLE stack, api)
+    "ecc_4k": (3840, 2160, 256, "ecc"),                 # BASELINE configs[3] — the metric's configuration
+    "ecc_1080p": (1920, 1080, 64, "ecc"),               # configs[2]
+    "keypoint_1080p": (1920, 1080, 64, "keypoint"),     # configs[1]
     "ecc_small": (640, 480, 8, "ecc"),
-    # BASELINE configs[4] (an extension beyond the reference): 16-bit 4K stack, ORB-seeded ECC refine
-    "hybrid_4k16": (3840, 2160, 32, "hybrid"),
+    # BASELINE configs[4] (an extension beyond the reference): 16-bit 4K stack, ORB-seeded ECC refine; 1024 frames in
+    # BASELINE, 256 here so that the u16 stack (12.7 GB) + templates + ORB workspace fit next to each other comfortably
+    "hybrid_4k16": (3840, 2160, 256, "hybrid"),
 }
 
 
@@ -87,10 +90,11 @@ def main() -> None:
     from libstacker_rs_amd import (EccMatchParameters, KeyPointMatchParameters, MotionType, RANSAC, Stacker, synth)
     from libstacker_rs_amd.shard import shard_moving_frames
 
-    W, H, fpg, api = WORKLOADS[args.workload]
+    W, H, n_global, api = WORKLOADS[args.workload]      # frames in the whole stack (frame 0 = reference)
+    scaling = "strong"
     if args.frames_per_gpu > 0:
-        fpg = args.frames_per_gpu
-    n_global = fpg * world                       # frames in the whole stack (frame 0 = reference)
+        n_global, scaling = args.frames_per_gpu * world, "weak"
+    fpg = n_global / world
     # contiguous shards of the moving frames 1..n-1; rank 0 also folds frame 0 itself in
     mine = shard_moving_frames(n_global, world, rank)
 
@@ -215,14 +219,14 @@ def main() -> None:
             "metric": "frames/sec aligned+stacked (4K RGB, ECC homography)" if args.workload == "ecc_4k"
                       else f"frames/sec aligned+stacked ({args.workload})",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n_global}-frame {W}x{H} BGR {'u16' if api == 'hybrid' else 'u8'} stack, "
                                    + ("ORB-seeded ecc_match (extension, 16-bit) Homography max_count 5000 eps 1e-5 gauss 5" if api == "hybrid" else
                                       "ecc_match Homography max_count 5000 eps 1e-5 gauss 5" if api == "ecc"
                                       else "keypoint_match RANSAC thr 5.0 ratio 0.9 keep 0.80")
-                                   + f", {fpg} frames/GPU resident in HBM, frame-sharded, one accumulator reduce",
-                       "frames_per_gpu": fpg, "width": W, "height": H, "parallelism": f"frame-shard x{world}",
+                                   + f", {fpg:g} frames/GPU resident in HBM, frame-sharded, one accumulator reduce",
+                       "frames_per_gpu": fpg, "frames_total": n_global, "width": W, "height": H, "parallelism": f"frame-shard x{world}",
                        "accumulator_reduce": ("none (1 GPU)" if world == 1 else
                                               "RCCL reduce to rank 0, overlapped with the next step's alignment (double-buffered)"
                                               if overlap else "RCCL reduce to rank 0, waited for before the next step")},

@@ -12,8 +12,10 @@
  *  - `location` says whether a pointer is host (0) or device/HBM (1) memory.
  *  - Every entry point returns an `stk_status`; the message of the last
  *    failure is available from stk_last_error(). Nothing throws or aborts.
- *  - A `stk_ctx` owns one GPU, one HIP stream and the HBM workspace; one call
- *    at a time per context, any number of contexts per process.
+ *  - A `stk_ctx` owns one GPU, one HIP stream and the HBM workspace — or, made
+ *    with stk_create_multi, several GPUs of the node (one host thread, stream
+ *    and workspace per GPU, RCCL communicators for the accumulator reduce);
+ *    one call at a time per context, any number of contexts per process.
  *
  * Reference citations are `file:line` under the reference checkout
  * (`src/lib.rs`, `src/utils.rs`).
@@ -124,6 +126,22 @@ typedef struct stk_ctx stk_ctx;
 
 /* ---- context ------------------------------------------------------------ */
 stk_status  stk_create(int32_t device_id, stk_ctx** out);
+/* One context over n_devices GPUs of this node: what a single-process caller (the Rust drop-in) uses to stack on all of
+ * them. stk_keypoint_match / stk_ecc_match / stk_hybrid_match (and the *_files forms) then cut the moving frames 1..n-1
+ * into contiguous ranges, one per device (stk_shard_moving_frames; replaces the Rayon fold, lib.rs:188-320, 746-818),
+ * run one host thread per device, sum the f32 accumulators and the {added, dropped} counters on device_ids[0] with
+ * RCCL ncclReduce over xGMI (replaces try_reduce, lib.rs:321-335, 819-833) and scale there (lib.rs:339-345, 836-839).
+ * Frames may be host memory or device memory on any of the devices (frames on another device are copied over once).
+ * Per-frame results are bit-identical to the single-device run as long as every range holds at least "ecc_slots"
+ * frames; the image differs by the order of the f32 adds only. n_devices == 1 returns a plain context. Stage-level and
+ * *_shard entry points on such a context run on device_ids[0]. RCCL (librccl.so.1) is loaded at this call. */
+stk_status  stk_create_multi(int32_t n_devices, const int32_t* device_ids, stk_ctx** out);
+/* The cut itself: rank `rank` of `world_size` aligns frames [first, first + count) of an n_frames stack (frame 0 is the
+ * reference and belongs to nobody's range; rank 0 folds it in). Sizes differ by at most one, earlier ranks are larger. */
+stk_status  stk_shard_moving_frames(int32_t n_frames, int32_t world_size, int32_t rank, int32_t* first, int32_t* count);
+/* Loads RCCL, sum-reduces `count` floats over the context's devices (a 1-rank communicator on a plain context) and
+ * verifies the result on the root: the part of the multi-device path that a one-GPU machine can still execute. */
+stk_status  stk_rccl_selftest(stk_ctx* ctx, int64_t count);
 void        stk_destroy(stk_ctx* ctx);
 const char* stk_last_error(const stk_ctx* ctx);    /* valid until the next call on ctx */
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL

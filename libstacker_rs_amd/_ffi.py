@@ -54,6 +54,9 @@ class Timing(C.Structure):
 SIGNATURES = {
     "stk_version": (C.c_char_p, []),
     "stk_create": (c_status, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "stk_create_multi": (c_status, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "stk_shard_moving_frames": (c_status, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "stk_rccl_selftest": (c_status, [C.c_void_p, C.c_int64]),
     "stk_destroy": (None, [C.c_void_p]),
     "stk_last_error": (C.c_char_p, [C.c_void_p]),
     "stk_set_stream": (c_status, [C.c_void_p, C.c_void_p]),

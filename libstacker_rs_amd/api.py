@@ -111,19 +111,6 @@ def _is_torch(x) -> bool:
 _DEPTH = {"uint8": 8, "uint16": 16, "float32": 32}
 
 
-# Device tensors handed to the engine must be complete on the engine's stream. Unless a Stacker has been bound to
-# torch's current stream (use_torch_stream), work queued on torch's stream (an index op, a clone, an in-place add that
-# produced the tensor) is drained before the pointers cross the C ABI.
-_BOUND_TO_TORCH_STREAM = False
-
-
-def _torch_inputs_ready():
-    if not _BOUND_TO_TORCH_STREAM:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()
-
-
 class _Marshalled:
     """Pointers + geometry of a frame stack, keeping the owners alive."""
 
@@ -137,13 +124,16 @@ class _Marshalled:
         self.n = len(frames)
         self.location = HOST
         self.torch_device = None
+        self.devices = set()
         ptrs = []
         geo = None
         for f in frames:
             if _is_torch(f):
                 if f.is_cuda:
                     self.location = DEVICE
-                    self.torch_device = f.device
+                    if self.torch_device is None:
+                        self.torch_device = f.device         # outputs go where the reference frame lives
+                    self.devices.add(f.device)
                     t = f.contiguous()
                     self.keep.append(t)
                     ptrs.append(t.data_ptr())
@@ -175,21 +165,52 @@ class _Marshalled:
         self.ptr_arr = (C.c_void_p * max(self.n, 1))(*ptrs)
         self.c_frames = _ffi.Frames(C.cast(self.ptr_arr, C.POINTER(C.c_void_p)), self.n, self.w, self.h, self.c,
                                     self.depth, self.location, 0)
-        if self.location == DEVICE:
-            _torch_inputs_ready()
 
 
 class Stacker:
-    """One GPU context (stk_ctx). Not thread-safe: one call at a time per instance."""
+    """One engine context (stk_ctx): one GPU, or — `devices=[...]` — several GPUs of the node behind ONE context, the
+    moving frames sharded over them and the accumulators reduced with RCCL inside the library (stk_create_multi).
+    Not thread-safe: one call at a time per instance."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices: Optional[Sequence[int]] = None):
         self._lib = _ffi.load()
         h = C.c_void_p()
-        st = self._lib.stk_create(int(device), C.byref(h))
+        if devices is not None:
+            ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            st = self._lib.stk_create_multi(len(devices), ids, C.byref(h))
+            device = int(devices[0]) if len(devices) else 0
+        else:
+            st = self._lib.stk_create(int(device), C.byref(h))
         if st != 0:
-            raise HipError(f"stk_create(device={device}) failed with status {st} (no usable GPU?)")
+            raise HipError(f"stk_create(device={device}, devices={devices}) failed with status {st} (no usable GPU?)")
         self._h = h
         self.device = int(device)
+        self.devices = [int(d) for d in devices] if devices is not None else [int(device)]
+        self._bound_stream = None          # cuda_stream handle of the torch stream this context runs on, if any
+
+    def _marshal(self, frames) -> "_Marshalled":
+        """Pointers of a frame stack; device tensors must be complete before the engine's stream reads them. If this
+        context runs ON torch's current stream of that device (use_torch_stream) stream order already guarantees it;
+        otherwise — an unbound context, a `with torch.cuda.stream(...)` block, another device — the producer streams
+        are drained first."""
+        m = _Marshalled(frames)
+        if m.location == DEVICE:
+            import torch
+            for d in m.devices:
+                cur = torch.cuda.current_stream(d)
+                if not (self._bound_stream is not None and d.index == self.device and cur.cuda_stream == self._bound_stream):
+                    cur.synchronize()
+        return m
+
+    def _tensor_ready(self, t):
+        import torch
+        cur = torch.cuda.current_stream(t.device)
+        if not (self._bound_stream is not None and t.device.index == self.device and cur.cuda_stream == self._bound_stream):
+            cur.synchronize()
+
+    def rccl_selftest(self, count: int = 1 << 20):
+        """Load RCCL, build a communicator over this context's devices and check a sum-reduce (stk_rccl_selftest)."""
+        self._check(self._lib.stk_rccl_selftest(self._h, int(count)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -213,12 +234,14 @@ class Stacker:
 
     def set_stream(self, stream_ptr: int | None):
         self._check(self._lib.stk_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        self._bound_stream = None
 
     def use_torch_stream(self):
-        global _BOUND_TO_TORCH_STREAM
+        """Run this context on torch's CURRENT stream of its device (captured now; call again after switching streams)."""
         import torch
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        _BOUND_TO_TORCH_STREAM = True
+        h = torch.cuda.current_stream(self.device).cuda_stream
+        self.set_stream(h)
+        self._bound_stream = h
 
     def timing(self) -> dict:
         t = _ffi.Timing()
@@ -245,7 +268,7 @@ class Stacker:
     # -- whole-stack API (the reference's two entry points) ---------------------------------------
     def ecc_match(self, files, params: EccMatchParameters, scale_down_width: Optional[float] = None,
                   return_stats: bool = False):
-        m = _Marshalled(files)
+        m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
         out, img = self._out_image(m)
@@ -258,7 +281,7 @@ class Stacker:
 
     def keypoint_match(self, files, params: KeyPointMatchParameters, scale_down_width: Optional[float] = None,
                        return_stats: bool = False):
-        m = _Marshalled(files)
+        m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
         out, img = self._out_image(m)
@@ -274,7 +297,7 @@ class Stacker:
     def ecc_match_shard(self, files, params: EccMatchParameters, add_reference: bool, sum_out,
                         scale_down_width: Optional[float] = None):
         """Un-normalised f32 sum of this rank's aligned frames into `sum_out` (cuda tensor HxWx3)."""
-        m = _Marshalled(files)
+        m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
         img = _ffi.ImageF32(sum_out.data_ptr(), m.w, m.h, 3, DEVICE, 0)
@@ -288,7 +311,7 @@ class Stacker:
 
     def keypoint_match_shard(self, files, params: KeyPointMatchParameters, add_reference: bool, sum_out,
                              scale_down_width: Optional[float] = None):
-        m = _Marshalled(files)
+        m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
         img = _ffi.ImageF32(sum_out.data_ptr(), m.w, m.h, 3, DEVICE, 0)
@@ -303,7 +326,7 @@ class Stacker:
 
     def finalize_mean(self, sum_img, n_frames: int, out=None):
         """img / n  (lib.rs:339-345, 836-839) on a cuda tensor; in place when out is None."""
-        _torch_inputs_ready()
+        self._tensor_ready(sum_img)
         h, w, c = sum_img.shape
         out = sum_img if out is None else out
         a = _ffi.ImageF32(sum_img.data_ptr(), w, h, c, DEVICE, 0)
@@ -313,7 +336,7 @@ class Stacker:
 
     # -- stage-level (parity tests) ------------------------------------------------------------------
     def grey(self, frame):
-        m = _Marshalled([frame])
+        m = self._marshal([frame])
         if m.location == DEVICE:
             import torch
             out = torch.empty((m.h, m.w), dtype=m.keep[0].dtype, device=m.torch_device)
@@ -325,7 +348,7 @@ class Stacker:
         return out
 
     def convert_f32(self, frame, alpha: float = 1.0 / 255.0):
-        m = _Marshalled([frame])
+        m = self._marshal([frame])
         if m.location == DEVICE:
             import torch
             out = torch.empty(tuple(m.keep[0].shape), dtype=torch.float32, device=m.torch_device)
@@ -339,7 +362,7 @@ class Stacker:
     # -- BASELINE configs[4] (extension): ORB-seeded ECC on 8- or 16-bit stacks --------------------------------
     def hybrid_match(self, files, kp_params: KeyPointMatchParameters, ecc_params: EccMatchParameters, return_stats=False):
         """ORB + RANSAC homography as the initial warp of findTransformECC; 16-bit frames folded with alpha 1/65535."""
-        m = _Marshalled(files)
+        m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
         out, img = self._out_image(m)
@@ -350,7 +373,7 @@ class Stacker:
 
     def hybrid_match_shard(self, files, kp_params: KeyPointMatchParameters, ecc_params: EccMatchParameters,
                            add_reference: bool, sum_out):
-        m = _Marshalled(files)
+        m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
         img = _ffi.ImageF32(sum_out.data_ptr(), m.w, m.h, 3, DEVICE, 0)
@@ -451,7 +474,7 @@ class Stacker:
 
     def grey_blur_f32(self, frame, ksize: int):
         """cvt_color(BGR2GRAY) + findTransformECC's GaussianBlur of one frame, fused (the per-frame ECC preparation)."""
-        m = _Marshalled([frame])
+        m = self._marshal([frame])
         if m.location == DEVICE:
             import torch
             out = torch.empty((m.h, m.w), dtype=torch.float32, device=m.torch_device)
@@ -490,7 +513,7 @@ class Stacker:
     def warp_accumulate(self, frame, M, *, is_affine=False, border_mode=BORDER_CONSTANT, border_value=(0, 0, 0, 0),
                         alpha=1.0 / 255.0, acc=None):
         """warp_perspective/warp_affine(convert(frame, alpha), M) (+ acc). Returns the f32 image."""
-        m = _Marshalled([frame])
+        m = self._marshal([frame])
         Md = np.ascontiguousarray(np.asarray(M, np.float64).reshape(-1))
         if Md.size == 6:
             Md = np.concatenate([Md, [0.0, 0.0, 1.0]])

@@ -24,6 +24,14 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
+namespace stk { struct MultiState; }
+void multi_destroy(stk_ctx* ctx);
+stk_status multi_match(stk_ctx* ctx, int kind, const stk_frames* frames, const stk_keypoint_params* kp, const stk_ecc_params* ep,
+                       float scale_down_width, stk_image_f32* out, int32_t* dropped_out, stk_frame_stats* stats);
+stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value);
+int multi_member_count(const stk_ctx* ctx);
+stk_ctx* multi_member(const stk_ctx* ctx, int i);
+
 struct stk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -47,7 +55,8 @@ struct stk_ctx {
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
     stk::KeypointWorkspace* kp = nullptr;
     stk::geom::HgWorkspace* hg = nullptr;   // findHomography batch workspace (homography.cpp)
-    stk::HostPool* host_pool = nullptr;   // persistent host threads of the keypoint path (keypoint.cpp)
+    stk::HostPool* host_pool = nullptr;
+    stk::MultiState* multi = nullptr;      // non-null: this context spans several devices (multi.cpp); it is member 0 itself   // persistent host threads of the keypoint path (keypoint.cpp)
     std::mutex err_mutex;
 };
 

@@ -53,6 +53,7 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
 
 stk_status stk_hybrid_match(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* kp_params,
                             const stk_ecc_params* ecc_params, stk_image_f32* out, stk_frame_stats* stats) {
+    if (ctx && ctx->multi) return multi_match(ctx, 2, frames, kp_params, ecc_params, 0.f, out, nullptr, stats);
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
     if ((st = image_check(ctx, out, frames->width, frames->height, 3))) return st;

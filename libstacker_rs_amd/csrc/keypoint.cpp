@@ -585,6 +585,7 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
 
 stk_status stk_keypoint_match(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params,
                               float scale_down_width, stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats) {
+    if (ctx && ctx->multi) return multi_match(ctx, 1, frames, params, nullptr, scale_down_width, out, dropped, stats);
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
     if ((st = image_check(ctx, out, frames->width, frames->height, 3))) return st;

@@ -89,6 +89,7 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
 
 void stk_destroy(stk_ctx* ctx) {
     if (!ctx) return;
+    multi_destroy(ctx);                    // the other devices' contexts, RCCL communicators
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->frames, &ctx->ref, &ctx->blur_tmp, &ctx->templates, &ctx->slots, &ctx->queue, &ctx->results,
@@ -121,6 +122,16 @@ stk_status stk_get_timing(const stk_ctx* ctx, stk_timing* out) {
 
 stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return STK_INVALID_PARAMS;
+    for (int i = 1; i < multi_member_count(ctx); i++) {          // a multi-device context: every device gets the knob
+        const stk_status st = set_option_one(multi_member(ctx, i), name, value);
+        if (st) return fail(ctx, st, stk_last_error(multi_member(ctx, i)));
+    }
+    return set_option_one(ctx, name, value);
+}
+
+}  // extern "C"
+
+stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "ecc_slots") { if (value < 0 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_slots out of range"); ctx->opt_ecc_slots = (int)value; }
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
@@ -134,7 +145,6 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
     return STK_OK;
 }
 
-}  // extern "C"
 
 float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
@@ -501,6 +511,7 @@ stk_status stk_finalize_mean(stk_ctx* ctx, const stk_image_f32* sum, int64_t n_f
 
 stk_status stk_ecc_match(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params,
                          float scale_down_width, stk_image_f32* out, stk_frame_stats* stats) {
+    if (ctx && ctx->multi) return multi_match(ctx, 0, frames, nullptr, params, scale_down_width, out, nullptr, stats);
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
     if ((st = image_check(ctx, out, frames->width, frames->height, 3))) return st;

@@ -46,7 +46,8 @@ def _worker(rank, world, port, frames, tmpdir):
         counts = torch.tensor([added, 0], dtype=torch.int64)
         shard.reduce_to_root(t_acc, counts)
         if rank == 0:
-            out = oracle.scale(t_acc.numpy(), int(counts[0]) - int(counts[1]))
+            # divisor = frames actually added over all ranks (= n - dropped: `added` never counts a dropped frame)
+            out = oracle.scale(t_acc.numpy(), int(counts[0]))
             np.save(os.path.join(tmpdir, "out.npy"), out)
             np.save(os.path.join(tmpdir, "counts.npy"), counts.numpy())
     finally:

@@ -225,3 +225,24 @@ def test_imread_tiff_through_runtime_libtiff(tmp_path, write_tiff):
         assert np.array_equal(out, img)
     (tmp_path / "bad.tif").write_bytes(b"II*\x00 not really a tiff")
     assert lib.stk_imread(None, os.fsencode(tmp_path / "bad.tif"), None, 0, None, None, None, None) == 4
+
+
+def test_shard_arithmetic_of_the_library_matches_shard_py():
+    """stk_shard_moving_frames (multi.cpp: the cut a multi-device context makes) == shard.py (the cut bench.py's
+    one-process-per-GPU ranks make): contiguous, complete, sizes within one, earlier ranks larger. No GPU needed."""
+    import ctypes as C
+    from libstacker_rs_amd import _ffi, shard
+    lib = _ffi.load()
+    for n in list(range(1, 40)) + [64, 256, 257, 1024]:
+        for world in (1, 2, 3, 4, 7, 8, 16):
+            covered = []
+            for rank in range(world):
+                first, count = C.c_int32(-1), C.c_int32(-1)
+                assert lib.stk_shard_moving_frames(n, world, rank, C.byref(first), C.byref(count)) == 0
+                mine = shard.shard_moving_frames(n, world, rank)
+                assert list(range(first.value, first.value + count.value)) == mine
+                covered += mine
+            assert covered == list(range(1, n))
+    f, c = C.c_int32(), C.c_int32()
+    assert lib.stk_shard_moving_frames(0, 2, 0, C.byref(f), C.byref(c)) == 2          # STK_INVALID_PARAMS
+    assert lib.stk_shard_moving_frames(5, 2, 2, C.byref(f), C.byref(c)) == 2
