@@ -57,6 +57,11 @@ def main() -> None:
     ap.add_argument("--no-reduce-overlap", action="store_true",
                     help="N > 1: wait for the accumulator reduce before starting the next step (default: the reduce of step k "
                          "runs under the alignment of step k+1, on a second accumulator)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 from ONE process: a multi-device context (stk_create_multi) shards, runs one host thread per GPU "
+                         "and reduces with RCCL inside the library — the call shape of the Rust drop-in. Launch WITHOUT torchrun.")
+    ap.add_argument("--host-fed-steps", type=int, default=2,
+                    help="N = 1: extra steps after the timed region with the stack in PINNED HOST memory (H2D included); 0 = skip")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the reduce goes through gloo/CPU "
                          "(checks the sharded code path, not a performance number)")
@@ -94,13 +99,21 @@ def main() -> None:
     scaling = "strong"
     if args.frames_per_gpu > 0:
         n_global, scaling = args.frames_per_gpu * world, "weak"
+    ecc_params = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
+    kp_params = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
+    depth = 16 if api == "hybrid" else 8
+    px = W * H
+
+    if args.single_process:
+        return single_process(args, torch, np, synth, Stacker, shard_moving_frames, W, H, n_global, api, depth, ecc_params, kp_params, scaling)
+
     fpg = n_global / world
     # contiguous shards of the moving frames 1..n-1; rank 0 also folds frame 0 itself in
     mine = shard_moving_frames(n_global, world, rank)
 
     t0 = time.time()
     scene = synth.render_scene(W, H)
-    frames, G = synth.make_stack(0, W, H, scene=scene, device=dev, indices=[0] + mine, depth=16 if api == "hybrid" else 8)
+    frames, G = synth.make_stack(0, W, H, scene=scene, device=dev, indices=[0] + mine, depth=depth)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 
@@ -114,9 +127,8 @@ def main() -> None:
     st.set_option("profile", 2 if args.profile_launches else 1)
     # an event pair around a launch keeps it from being dispatched back to back with its neighbours: bracketing every
     # launch costs ~5 % of `value`, so every 3rd launch is sampled (3 is coprime with the 4-launch polling chunk)
-    st.set_option("profile_stride", max(1, args.profile_launches if args.profile_launches > 1 else 3))
-    ecc_params = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
-    kp_params = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
+    stride = max(1, args.profile_launches if args.profile_launches > 1 else 3)
+    st.set_option("profile_stride", stride)
     # two accumulators: while step k's sum is being reduced over xGMI, step k+1 aligns into the other one
     accs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     cnts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(len(accs))]
@@ -126,8 +138,8 @@ def main() -> None:
     step_no = 0
     totals = [0, 0]                                  # frames folded / dropped in the last finished stack (rank 0)
 
-    agg = {"ecc_iter_ms": 0.0, "ecc_iter_timed": 0, "ecc_iter_launches": 0, "ecc_slot_iterations": 0, "prep_ms": 0.0, "align_ms": 0.0,
-           "warp_ms": 0.0, "warp_frames": 0, "warp_launches": 0}
+    agg = {k: 0 for k in ("ecc_iter_ms", "ecc_iter_timed", "ecc_iter_launches", "ecc_slot_iterations", "prep_ms", "align_ms", "warp_ms",
+                          "warp_frames", "warp_launches", "fast_ms", "fast_launches", "fast_pixels")}
     last_stats = None
 
     def start_reduce(acc, counts):
@@ -151,18 +163,20 @@ def main() -> None:
             totals[0], totals[1] = int(counts[0].item()), int(counts[1].item())
             st.finalize_mean(acc, totals[0], out)
 
+    def run_shard(src, acc):
+        if api == "ecc":
+            added, stats = st.ecc_match_shard(src, ecc_params, rank == 0, acc)
+            return added, 0, stats
+        if api == "hybrid":
+            added, stats = st.hybrid_match_shard(src, kp_params, ecc_params, rank == 0, acc)
+            return added, 0, stats
+        return st.keypoint_match_shard(src, kp_params, rank == 0, acc)
+
     def step(record: bool):
         nonlocal last_stats, pending, step_no
         acc, counts = accs[step_no % len(accs)], cnts[step_no % len(accs)]
         step_no += 1
-        if api == "ecc":
-            added, stats = st.ecc_match_shard(frames, ecc_params, rank == 0, acc)
-            dropped = 0
-        elif api == "hybrid":
-            added, stats = st.hybrid_match_shard(frames, kp_params, ecc_params, rank == 0, acc)
-            dropped = 0
-        else:
-            added, dropped, stats = st.keypoint_match_shard(frames, kp_params, rank == 0, acc)
+        added, dropped, stats = run_shard(frames, acc)
         if record:
             t = st.timing()
             for k in agg:
@@ -209,93 +223,211 @@ def main() -> None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    frames_per_step = n_global
-    value = frames_per_step * args.steps / elapsed
+    value = n_global * args.steps / elapsed
 
     if rank == 0:
-        px = W * H
-        res = {
-            "metric": "frames/sec aligned+stacked (4K RGB, ECC homography)" if args.workload == "ecc_4k"
-                      else f"frames/sec aligned+stacked ({args.workload})",
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n_global}-frame {W}x{H} BGR {'u16' if api == 'hybrid' else 'u8'} stack, "
-                                   + ("ORB-seeded ecc_match (extension, 16-bit) Homography max_count 5000 eps 1e-5 gauss 5" if api == "hybrid" else
-                                      "ecc_match Homography max_count 5000 eps 1e-5 gauss 5" if api == "ecc"
-                                      else "keypoint_match RANSAC thr 5.0 ratio 0.9 keep 0.80")
-                                   + f", {fpg:g} frames/GPU resident in HBM, frame-sharded, one accumulator reduce",
-                       "frames_per_gpu": fpg, "frames_total": n_global, "width": W, "height": H, "parallelism": f"frame-shard x{world}",
-                       "accumulator_reduce": ("none (1 GPU)" if world == 1 else
-                                              "RCCL reduce to rank 0, overlapped with the next step's alignment (double-buffered)"
-                                              if overlap else "RCCL reduce to rank 0, waited for before the next step")},
-        }
-        # ---- roofline of the dominant kernel --------------------------------------------------
+        res = result_header(args, value, elapsed, world, scaling, api, W, H, n_global, fpg,
+                            "none (1 GPU)" if world == 1 else
+                            "RCCL reduce to rank 0, overlapped with the next step's alignment (double-buffered)" if overlap
+                            else "RCCL reduce to rank 0, waited for before the next step", f"frame-shard x{world}, one process per GPU")
+        src_b = 3 * px * (2 if depth == 16 else 1)
+        kernels = []
+        # ---- roofline of the dominant kernel and of the others on the path (live HIP-event timings of THIS run) ----
         if api in ("ecc", "hybrid") and agg["ecc_iter_timed"] > 0:
-            # ECC iteration kernel: ALGORITHMIC bytes = 16 B/px per frame-iteration (template 4 B +
-            # frame-0 image/gx/gy 12 B); one launch advances `slots` frames by one iteration.
+            # ECC iteration kernel: ALGORITHMIC bytes = 16 B/px per frame-iteration (template 4 B + frame-0 image/gx/gy
+            # 12 B); one launch advances up to `slots` frames by one iteration.
             alg_bytes_total = 16.0 * px * agg["ecc_slot_iterations"]
             launches = agg["ecc_iter_launches"]                     # every launch of the timed region (incl. drained no-ops)
-            avg_ms = agg["ecc_iter_ms"] / agg["ecc_iter_timed"]     # event-timed sample: every 3rd of them
+            avg_ms = agg["ecc_iter_ms"] / agg["ecc_iter_timed"]     # event-timed sample of them
             achieved = (alg_bytes_total / launches) / (avg_ms * 1e-3) / 1e9
-            # HBM-side traffic per launch from the PMC passes of the SAME command (tools/profile_round.sh,
-            # separate FETCH_SIZE / WRITE_SIZE passes; summary committed under profiles/): FETCH_SIZE is
-            # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 (the float4 scale_kernel in the same
-            # run calibrates exactly 1/2), WRITE_SIZE is taken as reported. null if no summary is present.
-            traffic = None
-            if args.workload == "ecc_4k" and world == 1 and not args.opt and not args.ecc_slots:
-                try:
-                    allk = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
-                    pm = next(v for k, v in allk.items() if k.startswith("stk::ecc_iter_h8_kernel"))
-                    traffic = round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1)
-                except Exception:
-                    traffic = None
-            res["roofline"] = {"kernel": "ecc_iter_h8_kernel (ECC iteration pass, homography)", "bound": "hbm", "achieved": round(achieved, 1),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": traffic, "traffic_source": "rocprofv3 --pmc (profiles/r01/pmc_summary.json)" if traffic else None,
-                               "avg_launch_ms": round(avg_ms, 5), "launches": launches, "launches_timed": agg["ecc_iter_timed"],
-                               "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
+            traffic, tsrc = pmc_traffic(args, world, "stk::ecc_iter_h8_kernel")
+            res["roofline"] = {
+                "kernel": "ecc_iter_h8_kernel (ECC iteration pass, homography)",
+                # `bound` names the roofline the figure is priced against (the contract's vocabulary: hbm | mfma); what
+                # actually limits the kernel is VALU issue (~92 instructions per pixel, ablation in DESIGN.md 4.7)
+                "bound": "hbm", "limiter": "valu-issue",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_ms": round(avg_ms, 5), "launches": launches, "launches_timed": agg["ecc_iter_timed"],
+                "timing": f"HIP event pair around every {stride}{'rd' if stride == 3 else 'th'} launch of the timed region, engine stream "
+                          "(rocprofv3 --kernel-trace mean over ALL launches of the same command: profiles/)",
+                "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
+            kernels.append({"kernel": "ecc_iter_h8_kernel", "bytes": "16 B/px/frame-iteration", "GBps": round(achieved, 1),
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(avg_ms * launches / args.steps, 3)})
+        if agg["warp_ms"] > 0:
+            # fused fold: every frame's source read once + the accumulator written once per launch (no read: the launch
+            # overwrites); SURVEY 8d's per-frame figure (source + accumulator read + write for EVERY frame) is the unfused cost
+            wb = agg["warp_frames"] * src_b + agg["warp_launches"] * 12 * px
+            g = wb / agg["warp_ms"] / 1e6
+            kernels.append({"kernel": "warp_accumulate_%s" % ("u16c3" if depth == 16 else "u8c3"),
+                            "bytes": "frames x %d B/px source + 12 B/px accumulator write per launch" % (src_b // px),
+                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(agg["warp_ms"] / args.steps, 3)})
+        if api == "ecc" and agg["prep_ms"] > 0:
+            pb = (src_b + 4 * px) * (frames.shape[0] - 1) * args.steps + (src_b + 24 * px) * args.steps
+            g = pb / agg["prep_ms"] / 1e6
+            kernels.append({"kernel": "grey_blur_u8c3 (+ ref_planes once)", "bytes": "3 B/px read + 4 B/px template write per frame",
+                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(agg["prep_ms"] / args.steps, 3)})
+        if agg["fast_ms"] > 0:
+            # FAST-9/16 + NMS + Harris short list over the 8 pyramid levels: reads each level's u8 pixels once
+            g = agg["fast_pixels"] / agg["fast_ms"] / 1e6
+            kernels.append({"kernel": "fast_nms_tiled_kernel (8 level launches per batch)", "bytes": "1 B/px of every pyramid level",
+                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(agg["fast_ms"] / args.steps, 3),
+                            "limiter": "integer VALU (ring tests)"})
+        if api == "keypoint" and kernels:
+            k = kernels[-1]
+            res["roofline"] = {"kernel": k["kernel"], "bound": "hbm", "limiter": "valu-issue", "achieved": k["GBps"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": k["frac"], "traffic": None,
+                               "timing": "HIP events around the 8 level launches of every ORB batch, engine stream"}
+        res["kernels"] = kernels
         its = [s["iterations"] for s in (last_stats or [])[1:]]
-        src_b = 3 * px
-        warp_bytes = (agg["warp_frames"] * src_b + agg["warp_launches"] * 2 * 12 * px)
         res["stages"] = {
             "prep_ms_per_step": round(agg["prep_ms"] / args.steps, 3),
             "align_ms_per_step": round(agg["align_ms"] / args.steps, 3),
             "warp_ms_per_step": round(agg["warp_ms"] / args.steps, 3),
             "ecc_iterations_mean": round(float(np.mean(its)), 2) if its else None,
             "ecc_iterations_max": int(max(its)) if its else None,
-            "warp_accumulate_GBps_fused": round(warp_bytes / max(agg["warp_ms"], 1e-9) / 1e6, 1),
-            "warp_accumulate_GBps_survey_bytes": round(agg["warp_frames"] * (src_b + 24 * px) / max(agg["warp_ms"], 1e-9) / 1e6, 1),
             "synthetic_generation_s": round(gen_s, 1),
             "frames_folded_last_step": totals[0], "frames_dropped_last_step": totals[1],
         }
+        # ---- host-fed: the same stack in PINNED HOST memory, H2D inside the timed region (SURVEY 8d metric ii) ----
+        if world == 1 and args.host_fed_steps > 0:
+            host = frames.cpu().pin_memory()
+            run_shard(host, accs[0])                                        # warm-up: staging buffers, first-touch
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            h2d_ms = h2d_b = 0.0
+            for _ in range(args.host_fed_steps):
+                added, dropped, _ = run_shard(host, accs[0])
+                st.finalize_mean(accs[0], added, out)
+                t = st.timing()
+                h2d_ms += t["h2d_ms"]; h2d_b += t["h2d_bytes"]
+            torch.cuda.synchronize()
+            eh = time.perf_counter() - th
+            link = h2d_b / max(h2d_ms, 1e-9) / 1e6
+            res["host_fed"] = {"value": round(n_global * args.host_fed_steps / eh, 3), "unit": "frames/s", "steps": args.host_fed_steps,
+                               "ms_per_step": round(1e3 * eh / args.host_fed_steps, 3),
+                               "h2d_GBps": round(link, 2), "h2d_ms_per_step": round(h2d_ms / args.host_fed_steps, 3),
+                               # a step cannot finish before its bytes have crossed the link: frames / h2d time = the PCIe-bound ceiling
+                               "pcie_bound_ceiling": round(n_global * args.host_fed_steps / (h2d_ms * 1e-3), 1) if h2d_ms > 0 else None,
+                               "frac_of_pcie_ceiling": round((n_global * args.host_fed_steps / eh) / (n_global * args.host_fed_steps / (h2d_ms * 1e-3)), 3) if h2d_ms > 0 else None,
+                               "note": "frames in pinned host memory; copy stream -> prep stream -> gated ECC queue; never `value`"}
+            del host
         # ---- CPU baseline: the oracle (a port of the reference's OpenCV/Rayon path) on host cores ----
         if not args.no_cpu_baseline and world == 1:
-            import oracle
-            cores = os.cpu_count() or 1
-            use = min(cores, 32)
-            n_s = args.cpu_sample_frames or (use + 1)
-            n_s = max(2, min(n_s, frames.shape[0]))
-            sample = [f.cpu().numpy() for f in frames[:n_s]]
-            tc = time.perf_counter()
-            if api == "ecc":
-                oracle.ecc_match(sample, max_count=5000, epsilon=1e-5, gauss_filt_size=5, n_threads=use)
-            elif api == "hybrid":
-                use, sample = 1, sample[:3]                     # the oracle's hybrid path is a serial Python composition
-                n_s = len(sample)
-                oracle.hybrid_match(sample)
-            else:
-                oracle.keypoint_match(sample, n_threads=use)
-            cpu_s = time.perf_counter() - tc
-            res["cpu_baseline"] = {"value": round(n_s / cpu_s, 4), "unit": "frames/s", "cores": use, "kind": "port",
-                                   "sample": f"first {n_s} frames of the same {W}x{H} stack, one oracle pass ({cpu_s:.1f} s), "
-                                             + ("serial Python composition of the oracle's stages" if api == "hybrid"
-                                                else "frame-parallel OpenMP like the reference's Rayon fold")}
+            res["cpu_baseline"] = cpu_baseline(args, api, frames, W, H)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def result_header(args, value, elapsed, world, scaling, api, W, H, n_global, fpg, reduce_desc, parallelism):
+    return {
+        "metric": "frames/sec aligned+stacked (4K RGB, ECC homography)" if args.workload == "ecc_4k"
+                  else f"frames/sec aligned+stacked ({args.workload})",
+        "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n_global}-frame {W}x{H} BGR {'u16' if api == 'hybrid' else 'u8'} stack"
+                               + (" = BASELINE configs[3]" if args.workload == "ecc_4k" and n_global == 256 else "") + ", "
+                               + ("ORB-seeded ecc_match (extension, 16-bit) Homography max_count 5000 eps 1e-5 gauss 5" if api == "hybrid" else
+                                  "ecc_match Homography max_count 5000 eps 1e-5 gauss 5" if api == "ecc"
+                                  else "keypoint_match RANSAC thr 5.0 ratio 0.9 keep 0.80")
+                               + f", {fpg:g} frames/GPU resident in HBM, frame-sharded, one accumulator reduce",
+                   "frames_per_gpu": fpg, "frames_total": n_global, "width": W, "height": H, "parallelism": parallelism,
+                   "accumulator_reduce": reduce_desc},
+    }
+
+
+def pmc_traffic(args, world, kernel_prefix):
+    """HBM-side traffic per launch of the dominant kernel from the PMC passes of the SAME command (tools/profile_round.sh:
+    separate FETCH_SIZE / WRITE_SIZE passes, summary committed under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950 (calibrated in the same run on the float4 scale kernel AND on the byte-stream grey kernel),
+    WRITE_SIZE as reported. The summary records the SHA-256 of the kernel source it was taken with: a profile of an
+    older kernel is ignored (null) rather than reported."""
+    import hashlib
+    if args.workload != "ecc_4k" or world != 1 or args.opt or args.ecc_slots or args.frames_per_gpu:
+        return None, None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+        try:
+            allk = json.load(open(path))
+            pm = next(v for k, v in allk.items() if k.startswith(kernel_prefix))
+            want = allk.get("_kernel_source_sha256")
+            have = hashlib.sha256(open(os.path.join(ROOT, "libstacker_rs_amd", "csrc", "kernels_ecc.hip"), "rb").read()).hexdigest()
+            if want is not None and want != have:
+                return None, f"profiles/{rnd}/pmc_summary.json is from an older kernels_ecc.hip: ignored"
+            if want is None and rnd == "r01":
+                return None, "profiles/r01/pmc_summary.json predates this round's kernel: ignored"
+            return round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1), \
+                f"rocprofv3 --pmc, same command (profiles/{rnd}/pmc_summary.json)"
+        except Exception:
+            continue
+    return None, None
+
+
+def cpu_baseline(args, api, frames, W, H):
+    import oracle
+    cores = os.cpu_count() or 1
+    use = min(cores, 32)
+    n_s = args.cpu_sample_frames or (use + 1)
+    n_s = max(2, min(n_s, frames.shape[0]))
+    sample = [f.cpu().numpy() for f in frames[:n_s]]
+    tc = time.perf_counter()
+    if api == "ecc":
+        oracle.ecc_match(sample, max_count=5000, epsilon=1e-5, gauss_filt_size=5, n_threads=use)
+        how = f"frame-parallel OpenMP on {use} threads like the reference's Rayon fold"
+    elif api == "hybrid":
+        use, sample = 1, sample[:3]                     # the oracle's hybrid path is a serial Python composition of its stages
+        n_s = len(sample)
+        oracle.hybrid_match(sample)
+        how = "serial composition of the oracle's stages on 1 thread (no frame parallelism)"
+    else:
+        oracle.keypoint_match(sample, n_threads=use)
+        how = f"frame-parallel OpenMP on {use} threads like the reference's Rayon fold"
+    cpu_s = time.perf_counter() - tc
+    return {"value": round(n_s / cpu_s, 4), "unit": "frames/s", "cores": use, "kind": "port",
+            "sample": f"first {n_s} frames of the same {W}x{H} stack, one oracle pass ({cpu_s:.1f} s), {how}"}
+
+
+def single_process(args, torch, np, synth, Stacker, shard_moving_frames, W, H, n_global, api, depth, ecc_params, kp_params, scaling):
+    """N GPUs from ONE process through a multi-device context: the library shards, threads and reduces (RCCL) itself."""
+    n_dev = args.gpus
+    ids = [0] * n_dev if args.rehearse_on_one_gpu else list(range(n_dev))
+    scene = synth.render_scene(W, H)
+    parts = [None] * n_global
+    for r in range(n_dev):                                   # every device's range resident on that device
+        mine = shard_moving_frames(n_global, n_dev, r)
+        idx = ([0] if r == 0 else []) + mine
+        if not idx:
+            continue
+        fr, _ = synth.make_stack(0, W, H, scene=scene, device=torch.device("cuda", ids[r]), indices=idx, depth=depth)
+        for k, g in enumerate(idx):
+            parts[g] = fr[k]
+    st = Stacker(devices=ids)
+
+    def step():
+        if api == "ecc":
+            return st.ecc_match(parts, ecc_params)
+        if api == "hybrid":
+            return st.hybrid_match(parts, kp_params, ecc_params)
+        return st.keypoint_match(parts, kp_params)[1]
+
+    def sync():
+        for d in set(ids):
+            torch.cuda.synchronize(d)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    res = result_header(args, n_global * args.steps / elapsed, elapsed, n_dev, scaling, api, W, H, n_global, n_global / n_dev,
+                        "RCCL ncclReduce inside the library (stk_create_multi)" if not args.rehearse_on_one_gpu
+                        else "members share one GPU: local adds (rehearsal)", f"frame-shard x{n_dev}, ONE process, one host thread per GPU")
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

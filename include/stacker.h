@@ -120,6 +120,14 @@ typedef struct {
     /* option "profile" = 2 brackets every ECC iteration launch with its own HIP event pair: */
     double  ecc_iter_ms;            /* sum of those launch durations */
     int64_t ecc_iter_timed;         /* number of launches measured */
+    /* host-fed stacks (frames->location == STK_HOST): the copy stream's wall time from the first copy's start to the
+     * last copy's end, and the bytes moved; 0 for device-resident stacks */
+    double  h2d_ms;
+    int64_t h2d_bytes;
+    /* keypoint path: time and launches of the dominant ORB kernel (FAST-9/16 + NMS, all pyramid levels), pixels scanned */
+    double  fast_ms;
+    int64_t fast_launches;
+    int64_t fast_pixels;
 } stk_timing;
 
 typedef struct stk_ctx stk_ctx;
@@ -148,6 +156,11 @@ const char* stk_last_error(const stk_ctx* ctx);    /* valid until the next call 
  * restores the context's own stream. */
 stk_status  stk_set_stream(stk_ctx* ctx, void* hip_stream);
 stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
+/* Pinned (page-locked) host memory for frames: stacks handed over in such buffers cross PCIe by DMA at link rate and
+ * overlap with the alignment of the frames that have already arrived (a decoder — the Rust shim's imread — writes into
+ * them directly). Pageable frames work too, at the HIP runtime's staging rate. */
+stk_status  stk_host_alloc(size_t bytes, void** out);
+void        stk_host_free(void* p);
 /* Tuning knobs. None changes a frame's warp or the stacked image except where noted:
  *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto from the frame size); on large
  *                        frames it sets the workgroups per frame, see "ecc_blocks"
@@ -159,7 +172,9 @@ stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
  *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table
  *                        (changes results: it selects the other OpenCV behaviour)
  *   "profile"            0 off, 1 per-stage events (stk_get_timing), 2 + event pairs around ECC launches
- *   "profile_stride"     with profile = 2: bracket every n-th ECC launch only */
+ *   "profile_stride"     with profile = 2: bracket every n-th ECC launch only
+ *   "upload_batch"       host-fed stacks: frames per host -> HBM batch (default 8); a batch is the unit the ECC queue
+ *                        and the batched ORB wait for */
 stk_status  stk_set_option(stk_ctx* ctx, const char* name, int64_t value);
 const char* stk_version(void);
 

@@ -47,7 +47,9 @@ class Timing(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("align_ms", C.c_double), ("warp_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("ecc_iter_launches", C.c_int64),
                 ("ecc_slot_iterations", C.c_int64), ("warp_launches", C.c_int64),
-                ("warp_frames", C.c_int64), ("ecc_iter_ms", C.c_double), ("ecc_iter_timed", C.c_int64)]
+                ("warp_frames", C.c_int64), ("ecc_iter_ms", C.c_double), ("ecc_iter_timed", C.c_int64),
+                ("h2d_ms", C.c_double), ("h2d_bytes", C.c_int64), ("fast_ms", C.c_double), ("fast_launches", C.c_int64),
+                ("fast_pixels", C.c_int64)]
 
 
 # every symbol include/stacker.h declares, with its signature
@@ -57,6 +59,8 @@ SIGNATURES = {
     "stk_create_multi": (c_status, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "stk_shard_moving_frames": (c_status, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stk_rccl_selftest": (c_status, [C.c_void_p, C.c_int64]),
+    "stk_host_alloc": (c_status, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "stk_host_free": (None, [C.c_void_p]),
     "stk_destroy": (None, [C.c_void_p]),
     "stk_last_error": (C.c_char_p, [C.c_void_p]),
     "stk_set_stream": (c_status, [C.c_void_p, C.c_void_p]),

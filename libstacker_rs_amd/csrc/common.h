@@ -59,7 +59,7 @@ struct EccQueue {
     int next_frame;     // next template index to hand to a free slot
     int n_frames;       // number of templates
     int frames_done;
-    int pad;
+    int ready;          // templates [0, ready) exist; raised by the prep stream while frames are still arriving over PCIe
 #ifdef STK_SOLVE_TIMING
     long long dbg[16];   // wall_clock64 phase deltas of the last solve of slot 0 (10 ns ticks), debug builds only
 #endif
@@ -132,7 +132,8 @@ hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, 
 hipError_t launch_sharpness(const void* grey, int depth, int w, int h, int metric, int ksize, void* partials, int n_blocks,
                             hipStream_t s);
 hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
-                           const float* init_warps /* n_frames*9 or null */, hipStream_t s);
+                           const float* init_warps /* n_frames*9 or null */, hipStream_t s, int ready0 = -1 /* -1: all */);
+hipError_t launch_ecc_set_ready(EccQueue* queue, int ready, hipStream_t s);
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s);
 hipError_t launch_scale(const float* in, float* out, size_t n, float scale, hipStream_t s);
 hipError_t launch_add(float* acc, const float* in, size_t n, hipStream_t s);

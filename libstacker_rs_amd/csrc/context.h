@@ -35,6 +35,11 @@ stk_ctx* multi_member(const stk_ctx* ctx, int i);
 struct stk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t copy_stream = nullptr;    // host -> HBM copies of host-fed stacks (upload.cpp)
+    hipStream_t prep_stream = nullptr;    // grey + blur of frames that arrive while the ECC queue is already running
+    std::vector<hipEvent_t> upload_events;
+    hipEvent_t gate_ev = nullptr;
+    int opt_upload_batch = 8;             // frames per host -> HBM batch
     std::string err;
     int opt_ecc_slots = 0;        // 0 = auto
     int opt_subpixel_bits = 0;

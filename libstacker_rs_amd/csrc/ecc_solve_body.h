@@ -13,9 +13,19 @@
 
 namespace stk {
 
+// Claim the next template for a free slot, if one has been prepared already (queue->ready is raised by the prep stream
+// while later frames are still crossing PCIe; device-resident stacks start with ready == n_frames). A slot that finds
+// nothing stays idle (frame = -1) and asks again at the next solve launch.
 __device__ inline void slot_take_next(EccSlot* sl, EccQueue* queue, const float* init_warps) {
-    const int nxt = atomicAdd(&queue->next_frame, 1);
-    if (nxt < queue->n_frames) {
+    const int avail = min(__hip_atomic_load(&queue->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), queue->n_frames);
+    int nxt = __hip_atomic_load(&queue->next_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool got = false;
+    while (nxt < avail) {
+        const int seen = atomicCAS(&queue->next_frame, nxt, nxt + 1);
+        if (seen == nxt) { got = true; break; }
+        nxt = seen;
+    }
+    if (got) {
         sl->frame = nxt;
         sl->iter = 0;
         for (int k = 0; k < 9; k++) sl->warp[k] = init_warps ? init_warps[(size_t)nxt * 9 + k] : ((k % 4 == 0) ? 1.f : 0.f);

@@ -63,7 +63,14 @@ __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motio
             if (lane == 0 && k < NS && frame >= 0) a.sums[(size_t)slot * ECC_MAX_SUMS + k] = v;
         }
     }
-    if (frame < 0) return;                                  // idle slot: all of its workgroups leave, no ticket is drawn
+    if (frame < 0) {                                        // idle slot: no ticket is drawn; one thread looks for a newly prepared frame
+        if (g == 0 && tid == 0) {
+            EccSlot* sl = a.slots + slot;
+            slot_take_next(sl, queue, init_warps);
+            if (sl->frame >= 0) sl->last_rho = 0;
+        }
+        return;
+    }
 #ifdef STK_SOLVE_TIMING
     const long long t_reduced = wall_clock64();
 #endif
@@ -91,9 +98,9 @@ hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, 
 }
 
 __global__ void ecc_init_kernel(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
-                                const float* init_warps) {
+                                const float* init_warps, int ready0) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    queue->next_frame = 0; queue->n_frames = n_frames; queue->frames_done = 0; queue->pad = 0;
+    queue->next_frame = 0; queue->n_frames = n_frames; queue->frames_done = 0; queue->ready = ready0 < 0 ? n_frames : ready0;
     for (int f = 0; f < n_frames; f++) { results[f].status = 3; results[f].iters = 0; results[f].rho = -1; }
     for (int s = 0; s < n_slots; s++) {
         tickets[s] = 0;
@@ -103,8 +110,16 @@ __global__ void ecc_init_kernel(EccSlot* slots, int n_slots, int* tickets, EccQu
 }
 
 hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
-                           const float* init_warps, hipStream_t s) {
-    ecc_init_kernel<<<1, 64, 0, s>>>(slots, n_slots, tickets, queue, n_frames, results, init_warps);
+                           const float* init_warps, hipStream_t s, int ready0) {
+    ecc_init_kernel<<<1, 64, 0, s>>>(slots, n_slots, tickets, queue, n_frames, results, init_warps, ready0);
+    return hipGetLastError();
+}
+
+__global__ void ecc_set_ready_kernel(EccQueue* queue, int ready) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(&queue->ready, ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+hipError_t launch_ecc_set_ready(EccQueue* queue, int ready, hipStream_t s) {
+    ecc_set_ready_kernel<<<1, 64, 0, s>>>(queue, ready);
     return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@
 #include "context.h"
 #include "homography.h"
 #include "host_pool.h"
+#include "upload.h"
 #include "orb_pattern.h"
 
 using namespace stk;
@@ -166,19 +167,25 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     for (int l = 1; l < ORB_LEVELS; l++)
         HIP_TRY(launch_resize_exact(pyr + g.pyr.ofs[l - 1], g.pyr.w[l - 1], g.pyr.h[l - 1], pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], s,
                                     n_frames, PT));
+    const bool timed = ctx->opt_profile >= 1;
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[6], s));
     for (int l = 0; l < ORB_LEVELS; l++) {
         const int lw = g.pyr.w[l], lh = g.pyr.h[l];
         if (lw <= 6 || lh <= 6) continue;
+        ctx->timing.fast_launches += 1;
+        ctx->timing.fast_pixels += (int64_t)lw * lh * n_frames;
         HIP_TRY(launch_fast_level(pyr + g.pyr.ofs[l], lw, lh, ORB_FAST_THRESHOLD, ORB_EDGE, 2 * g.nfeatures[l], score + g.pyr.ofs[l],
                                   st + l, ws->cand.as<OrbCandidate>() + g.cand_ofs[l], (int)g.cand_cap[l],
                                   ws->sel.as<OrbSelected>() + (size_t)l * ORB_SEL_CAP, ORB_SEL_CAP, g.umax, s,
                                   n_frames, PT, ORB_LEVELS, g.cand_total, SELF));
     }
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[7], s));
     HIP_TRY(hipMemcpyAsync(ws->host_states, st, sizeof(OrbLevelState) * ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, s));
     // the head of every short list in one strided copy (rows = (frame, level), ORB_PACK of ORB_SEL_CAP entries each)
     HIP_TRY(hipMemcpy2DAsync(ws->host_sel, sizeof(OrbSelected) * ORB_PACK, ws->sel.p, sizeof(OrbSelected) * ORB_SEL_CAP,
                              sizeof(OrbSelected) * ORB_PACK, (size_t)ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (timed) ctx->timing.fast_ms += ev_ms(ctx->ev[6], ctx->ev[7]);
     // rare: a level with more short-listed corners than ORB_PACK (many tied FAST scores) is fetched whole
     std::vector<std::vector<OrbSelected>> big((size_t)n_frames * ORB_LEVELS);
     for (int f = 0; f < n_frames; f++)
@@ -399,12 +406,24 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
         if (!scaled_size(w, h, scale_down_width, ew, eh)) return fail(ctx, STK_INVALID_PARAMS, "scale_down_width gives an empty image");
     }
 
-    if ((st = resolve_frames(ctx, frames, dev))) return st;      // device pointers of the frames, returned to the caller
-    const size_t rb = frame_row_bytes(frames);
+    // device pointers of the frames, returned to the caller. Host-fed stacks cross PCIe on the copy stream while the ORB
+    // batches that have arrived are processed: the ORB batch is then capped to two upload batches.
+    const size_t rb = frame_row_bytes(frames), fb = rb * (size_t)h;
+    const bool host_fed = frames->location == STK_HOST;
+    dev.resize(n);
+    AsyncUpload up;
+    if (host_fed) {
+        HIP_TRY(ctx->frames.reserve(fb * (size_t)n));
+        for (int i = 0; i < n; i++) dev[i] = ctx->frames.as<uint8_t>() + fb * (size_t)i;
+        if ((st = up.start(ctx, frames, ctx->frames.p, fb, ctx->opt_upload_batch))) return st;
+    } else {
+        for (int i = 0; i < n; i++) dev[i] = frames->data[i];
+    }
     OrbGeometry g;
     orb_geometry(ew, eh, g);
     // frames per ORB batch: the whole shard when it fits a 32 GiB workspace (it does for every BASELINE config), else chunks
-    const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)32 << 30) / orb_bytes_per_frame(g)));
+    int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)32 << 30) / orb_bytes_per_frame(g)));
+    if (host_fed) batch = std::min(batch, 1 + 2 * ctx->opt_upload_batch);
     if ((st = orb_prepare(ctx, ctx->kp, ew, eh, g, batch))) return st;
     KeypointWorkspace* ws = ctx->kp;
     hipStream_t s = ctx->stream;
@@ -441,6 +460,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     // independent of the others (lib.rs:185-290 is the body of a Rayon map).
     for (int b0 = 0; b0 < n; b0 += batch) {
         const int nb = std::min(batch, n - b0);
+        if (host_fed && (st = up.wait_frame(b0 + nb - 1, s))) return st;
         // level 0 of every pyramid of the batch: one launch when the frames are evenly spaced in memory (a tensor), else per frame
         bool even = !scaled && nb > 1;
         const ptrdiff_t fstep = nb > 1 ? (const uint8_t*)dev[b0 + 1] - (const uint8_t*)dev[b0] : 0;
@@ -528,6 +548,11 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
 
     if (n_ref_keypoints) *n_ref_keypoints = n0;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (host_fed) {
+        double h2d = 0;
+        if ((st = up.finish(&h2d))) return st;
+        ctx->timing.h2d_ms = h2d; ctx->timing.h2d_bytes = (int64_t)(fb * (size_t)n);
+    }
     return STK_OK;
 }
 

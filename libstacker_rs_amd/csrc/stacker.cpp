@@ -8,9 +8,11 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <mutex>
 
 #include "context.h"
+#include "upload.h"
 
 using namespace stk;
 
@@ -78,6 +80,9 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
     ctx->device = device_id;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->gate_ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     if (hipHostMalloc((void**)&ctx->host_done, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
@@ -102,6 +107,10 @@ void stk_destroy(stk_ctx* ctx) {
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->prof_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->host_done) (void)hipHostFree(ctx->host_done);
+    for (auto& e : ctx->upload_events) if (e) (void)hipEventDestroy(e);
+    if (ctx->gate_ev) (void)hipEventDestroy(ctx->gate_ev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -113,6 +122,13 @@ stk_status stk_set_stream(stk_ctx* ctx, void* hip_stream) {
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return STK_OK;
 }
+
+stk_status stk_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return STK_INVALID_PARAMS;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? STK_OK : STK_HIP_ERROR;
+}
+void stk_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 stk_status stk_get_timing(const stk_ctx* ctx, stk_timing* out) {
     if (!ctx || !out) return STK_INVALID_PARAMS;
@@ -140,6 +156,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ecc_variant") { if (value < 0 || value > 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0..3"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
+    else if (n == "upload_batch") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "upload_batch out of range"); ctx->opt_upload_batch = (int)value; }
     else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;
@@ -228,10 +245,17 @@ static stk_status ecc_prepare_reference(stk_ctx* ctx, const EccPlan& pl, const v
 }
 
 // run the device-side iteration queue to completion; results copied to `res`
+// `feed`, when given, is the producer of a host-fed stack: feed(false) enqueues the preparation of every batch of frames
+// that has arrived since the last call (raising the queue's ready count behind it) and returns the number of templates
+// whose preparation has been enqueued so far; feed(true) first blocks until at least one more batch has arrived.
+using EccFeed = std::function<stk_status(bool block, int* enqueued)>;
 static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, const float* init_warps_dev,
-                          std::vector<EccFrameResult>& res) {
+                          std::vector<EccFrameResult>& res, const EccFeed* feed = nullptr) {
     res.resize(pl.n_templates);
     if (pl.n_templates == 0) return STK_OK;
+    // for (i = 1; i <= nIter && fabs(rho - last_rho) >= eps; i++) with rho = -1, last_rho = -eps: not even the first
+    // iteration runs when |eps - 1| < eps, i.e. eps > 0.5 (and never for nIter < 1)
+    if (crit.n_iter >= 1 && !(std::fabs(-1.0 - (-crit.eps)) >= crit.eps)) crit.n_iter = 0;
     EccIterArgs a{};
     const float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
     const float* gxy = ctx->ref.as<float>() + 3 * pl.ref_plane_floats + 2 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
@@ -249,7 +273,16 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     EccQueue* q = ctx->queue.as<EccQueue>();
     EccFrameResult* r = ctx->results.as<EccFrameResult>();
     a.slot0 = 0;
-    HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, a.tickets, q, pl.n_templates, r, init_warps_dev, ctx->stream));
+    HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, a.tickets, q, pl.n_templates, r, init_warps_dev, ctx->stream, feed ? 0 : -1));
+    int fed = feed ? 0 : pl.n_templates;
+    if (feed) {
+        // the prep stream may raise `ready` only after the queue exists
+        HIP_TRY(hipEventRecord(ctx->gate_ev, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->prep_stream, ctx->gate_ev, 0));
+        stk_status fs = (*feed)(crit.n_iter >= 1 ? false : true, &fed);
+        if (fs) return fs;
+        while (crit.n_iter < 1 && fed < pl.n_templates) { if ((fs = (*feed)(true, &fed))) return fs; }   // no iterations: just drain the producer
+    }
     if (crit.n_iter >= 1) {
         // Enqueue chunks of (iterate, solve) launches; keep two chunks in flight and poll the
         // device-side completion counter behind each. Launches after completion are no-ops.
@@ -264,7 +297,14 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
             for (auto& e : ctx->prof_ev) HIP_TRY(hipEventCreate(&e));
         }
         ctx->host_done[0] = ctx->host_done[1] = 0;
+        int last_done = 0;
         while (!done) {
+            if (feed && fed < pl.n_templates) {
+                // everything prepared so far has been aligned and the two chunks in flight cannot find work: wait for PCIe
+                const bool starved = last_done >= fed && inflight == 0;
+                stk_status fs = (*feed)(starved, &fed);
+                if (fs) return fs;
+            }
             while (inflight < 2) {
                 for (int c = 0; c < chunk; c++) {
                     // per-launch timing (profile >= 2) brackets every `profile_stride`-th pixel pass with an event pair: an
@@ -285,8 +325,15 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
                 inflight++;
             }
             HIP_TRY(hipEventSynchronize(ctx->poll_ev[head]));
-            if (ctx->host_done[head] >= pl.n_templates) done = true;
+            last_done = ctx->host_done[head];
+            if (last_done >= pl.n_templates) done = true;
             head ^= 1; inflight--;
+            if (feed && !done && last_done >= fed && fed < pl.n_templates) {
+                // starved: let the chunk still in flight drain, then block on the producer at the top of the loop
+                while (inflight > 0) { HIP_TRY(hipEventSynchronize(ctx->poll_ev[head])); last_done = ctx->host_done[head]; head ^= 1; inflight--; }
+                launched = 0;                                   // idle polling does not count against the drain guard
+                continue;
+            }
             if (!done && launched > max_launches)
                 return fail(ctx, STK_PROCESSING_ERROR, "ECC queue did not drain (internal error)");
         }
@@ -391,31 +438,46 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
     timing_begin(ctx);
 
-    std::vector<const void*> dev;
-    if ((st = resolve_frames(ctx, frames, dev))) return st;
-    const size_t rb = frame_row_bytes(frames);
+    // Host-fed stacks cross PCIe in batches on the copy stream while the frames that have arrived are already being
+    // prepared (prep stream) and aligned (the ECC queue hands a slot only templates below its `ready` count).
+    const size_t rb = frame_row_bytes(frames), fb = rb * (size_t)h;
+    const bool host_fed = frames->location == STK_HOST;
+    std::vector<const void*> dev(n);
+    AsyncUpload up;
+    if (host_fed) {
+        HIP_TRY(ctx->frames.reserve(fb * (size_t)n));
+        for (int i = 0; i < n; i++) dev[i] = ctx->frames.as<uint8_t>() + fb * (size_t)i;
+        if ((st = up.start(ctx, frames, ctx->frames.p, fb, ctx->opt_upload_batch))) return st;
+    } else {
+        for (int i = 0; i < n; i++) dev[i] = frames->data[i];
+    }
+    auto bail = [&](stk_status e) { (void)up.finish(nullptr); return e; };      // never leave the helper thread behind
     EccPlan pl{};
-    if ((st = ecc_plan(ctx, ew, eh, n - 1, params->motion_type, pl))) return st;
+    if ((st = ecc_plan(ctx, ew, eh, n - 1, params->motion_type, pl))) return bail(st);
+    if (scaled) { hipError_t he = ctx->scratch.reserve((size_t)w * h + (size_t)ew * eh + 256); if (he != hipSuccess) return bail(fail(ctx, STK_HIP_ERROR, "scratch allocation failed")); }
+    uint8_t* gfull = ctx->scratch.as<uint8_t>();
+    uint8_t* gsmall = scaled ? gfull + (((size_t)w * h + 255) & ~(size_t)255) : nullptr;
+    // one moving frame's template on stream `s`: grey (-> scale_image) -> blur
+    auto prepare_template = [&](int i, hipStream_t s) -> stk_status {
+        float* t = ctx->templates.as<float>() + pl.templ_plane_stride * (size_t)(i - 1);
+        if (!scaled) { HIP_TRY(launch_grey_blur(dev[i], frames->depth, 3, w, h, rb, params->gauss_filt_size, t, pl.templ_row_stride, s)); return STK_OK; }
+        HIP_TRY(launch_grey(dev[i], 8, w, h, rb, gfull, s));
+        HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, s));
+        HIP_TRY(launch_grey_blur(gsmall, 8, 1, ew, eh, (size_t)ew, params->gauss_filt_size, t, pl.templ_row_stride, s));
+        return STK_OK;
+    };
+    auto prepare_reference = [&](hipStream_t s) -> stk_status {
+        if (!scaled) return ecc_prepare_reference(ctx, pl, dev[0], frames->depth, 3, rb, params->gauss_filt_size);
+        HIP_TRY(launch_grey(dev[0], 8, w, h, rb, gfull, s));
+        HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, s));
+        return ecc_prepare_reference(ctx, pl, gsmall, 8, 1, (size_t)ew, params->gauss_filt_size);
+    };
 
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (!scaled) {
-        if ((st = ecc_prepare_reference(ctx, pl, dev[0], frames->depth, 3, rb, params->gauss_filt_size))) return st;
-        for (int i = 1; i < n; i++)
-            HIP_TRY(launch_grey_blur(dev[i], frames->depth, 3, w, h, rb, params->gauss_filt_size,
-                                     ctx->templates.as<float>() + pl.templ_plane_stride * (i - 1), pl.templ_row_stride, ctx->stream));
-    } else {
-        // grey (full size) -> scale_image (INTER_AREA) -> blur on the small grey
-        HIP_TRY(ctx->scratch.reserve((size_t)w * h + (size_t)ew * eh + 256));
-        uint8_t* gfull = ctx->scratch.as<uint8_t>();
-        uint8_t* gsmall = gfull + (((size_t)w * h + 255) & ~(size_t)255);
-        for (int i = 0; i < n; i++) {
-            HIP_TRY(launch_grey(dev[i], 8, w, h, rb, gfull, ctx->stream));
-            HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, ctx->stream));
-            if (i == 0) { if ((st = ecc_prepare_reference(ctx, pl, gsmall, 8, 1, (size_t)ew, params->gauss_filt_size))) return st; }
-            else HIP_TRY(launch_grey_blur(gsmall, 8, 1, ew, eh, (size_t)ew, params->gauss_filt_size,
-                                          ctx->templates.as<float>() + pl.templ_plane_stride * (i - 1), pl.templ_row_stride, ctx->stream));
-        }
-    }
+    if (host_fed && (st = up.wait_batch(0, ctx->stream))) return bail(st);
+    if ((st = prepare_reference(ctx->stream))) return bail(st);
+    if (!host_fed)
+        for (int i = 1; i < n; i++) if ((st = prepare_template(i, ctx->stream))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     const float* seeds_dev = nullptr;
     if (seeds && n > 1) {
@@ -424,7 +486,34 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         seeds_dev = ctx->init_warps.as<float>();
     }
     std::vector<EccFrameResult> res;
-    if ((st = ecc_run(ctx, pl, crit, seeds_dev, res))) return st;
+    if (host_fed) {
+        // the scaled path shares one grey scratch between the streams, so its templates are prepared on the compute
+        // stream itself (still batch by batch as they arrive); the full-size path uses the prep stream
+        hipStream_t ps = scaled ? ctx->stream : ctx->prep_stream;
+        int next_batch = 1, enq = 0;
+        EccQueue* q = ctx->queue.as<EccQueue>();
+        const EccFeed feed = [&](bool block, int* enqueued) -> stk_status {
+            while (next_batch < up.batches() && (block || up.recorded() > next_batch)) {
+                stk_status fs = up.wait_batch(next_batch, ps);
+                if (fs) return fs;
+                for (int k = 0; k < up.batch_count(next_batch); k++)
+                    if ((fs = prepare_template(up.batch_first(next_batch) + k, ps))) return fs;
+                enq = up.batch_first(next_batch) + up.batch_count(next_batch) - 1;        // templates 0 .. enq-1 exist
+                HIP_TRY(launch_ecc_set_ready(q, enq, ps));
+                next_batch++;
+                block = false;
+            }
+            *enqueued = enq;
+            return STK_OK;
+        };
+        st = ecc_run(ctx, pl, crit, seeds_dev, res, &feed);
+        double h2d = 0;
+        const stk_status fin = up.finish(&h2d);
+        if (st) return st;
+        if (fin) return fin;
+        ctx->timing.h2d_ms = h2d; ctx->timing.h2d_bytes = (int64_t)(fb * (size_t)n);
+        HIP_TRY(hipStreamSynchronize(ctx->prep_stream));
+    } else if ((st = ecc_run(ctx, pl, crit, seeds_dev, res))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
 
     const int is_affine = params->motion_type != STK_MOTION_HOMOGRAPHY;

@@ -109,3 +109,39 @@ def test_16bit_tiff_stack_through_hybrid_match_files(stacker, tmp_path, write_ti
     assert np.array_equal(stacker.hybrid_match_files(paths, kp, ecc), stacker.hybrid_match(list(f16), kp, ecc))
     with pytest.raises(OpenCvError):                        # the reference's own entry points reject 16-bit stacks
         stacker.ecc_match_files(paths, ecc)
+
+
+def test_host_fed_pipeline_equals_device_resident(stacker):
+    """Frames handed over in host memory cross PCIe in batches while earlier batches are prepared and aligned (copy
+    stream -> prep stream -> gated ECC queue / batched ORB); results must not depend on where the frames were or on how
+    the batches fell: bit-identical to the device-resident run, pinned or pageable, any batch size."""
+    import torch
+    from libstacker_rs_amd import EccMatchParameters, KeyPointMatchParameters, MotionType, RANSAC, synth
+    ecc = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    frames, _ = synth.make_stack(21, 320, 240)
+    dev = frames.cuda()
+    ref_e, st_e = stacker.ecc_match(dev, ecc, return_stats=True)
+    ref_k = stacker.keypoint_match(dev[:8], kp)
+    pinned = frames.pin_memory()
+    try:
+        for batch in (1, 3, 8, 64):
+            stacker.set_option("upload_batch", batch)
+            for src in (list(frames.numpy()), pinned):
+                out, st = stacker.ecc_match(src, ecc, return_stats=True)
+                assert np.array_equal(out if isinstance(out, np.ndarray) else out.cpu().numpy(), ref_e.cpu().numpy())
+                assert [s["iterations"] for s in st] == [s["iterations"] for s in st_e]
+            d, outk = stacker.keypoint_match(list(frames.numpy()[:8]), kp)
+            assert d == ref_k[0] and np.array_equal(outk, ref_k[1].cpu().numpy())
+        t = stacker.timing()
+        assert t["h2d_bytes"] == 8 * 320 * 240 * 3 and t["h2d_ms"] > 0
+        # scale-down variant and a single frame through the same route
+        a = stacker.ecc_match(list(frames.numpy()[:5]), ecc, scale_down_width=200.0)
+        b = stacker.ecc_match(dev[:5], ecc, scale_down_width=200.0).cpu().numpy()
+        assert np.array_equal(a, b)
+        assert np.array_equal(stacker.ecc_match([frames.numpy()[0]], ecc), stacker.ecc_match(dev[:1], ecc).cpu().numpy())
+        # eps > 0.5: OpenCV's loop test fails before the first iteration (rho = -1, last_rho = -eps): identity warps
+        o0, s0 = stacker.ecc_match(list(frames.numpy()[:3]), EccMatchParameters(MotionType.Homography, 50, 2.0, 5), return_stats=True)
+        assert all(s["iterations"] == 0 for s in s0) and np.array_equal(s0[1]["warp"], np.eye(3))
+    finally:
+        stacker.set_option("upload_batch", 8)
