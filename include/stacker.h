@@ -162,11 +162,11 @@ stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
 stk_status  stk_host_alloc(size_t bytes, void** out);
 void        stk_host_free(void* p);
 /* Tuning knobs. None changes a frame's warp or the stacked image except where noted:
- *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto from the frame size); on large
- *                        frames it sets the workgroups per frame, see "ecc_blocks"
- *   "ecc_blocks"         workgroups per ECC launch (default 1152); changes the f32 summation partition, i.e. results
- *                        at round-off level (within the stated ECC tolerance)
- *   "ecc_variant"        ECC pixel-pass kernel: 3 row-factorised (default), 0 direct, 1 LDS-tiled, 2 row-sharing
+ *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto: up to 32); changes no result
+ *   "ecc_blocks"         workgroups per ECC launch, all frames in flight together (0 = auto: 288 per frame); a non-zero
+ *                        value changes the f32 summation partition, i.e. results at round-off level (within the stated
+ *                        ECC tolerance)
+ *   "ecc_variant"        ECC pixel-pass kernel: 3 production (default), 0 the direct cross-check version
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
  *   "kp_workers"         host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
  *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table

@@ -109,6 +109,7 @@ struct WarpArgs {
     int accumulate;              // 0: overwrite, 1: acc += sum of warped frames
     int is_affine;
     int subpixel_bits;           // 0 or 5
+    int tune;                    // launch shape of the u8 fast path (option "warp_tune")
 };
 
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------
@@ -124,9 +125,8 @@ hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, si
 // blurred plane (stride in_stride) -> padded I/gx/gy planes
 hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
                              int ref_stride, hipStream_t s);
-// variant: 1 = LDS-tiled (64x16 tiles, double-buffered footprint), 0 = direct global gathers
+// variant: 3 = production kernels, 0 = direct cross-check version
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s);
-constexpr int ECC_TILE_W = 64, ECC_TILE_H = 16;
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
                             EccFrameResult* results, hipStream_t s, const float* init_warps = nullptr);
 hipError_t launch_sharpness(const void* grey, int depth, int w, int h, int metric, int ksize, void* partials, int n_blocks,

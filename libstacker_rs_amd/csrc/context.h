@@ -39,6 +39,7 @@ struct stk_ctx {
     hipStream_t prep_stream = nullptr;    // grey + blur of frames that arrive while the ECC queue is already running
     std::vector<hipEvent_t> upload_events;
     hipEvent_t gate_ev = nullptr;
+    int opt_warp_tune = 0;
     int opt_upload_batch = 8;             // frames per host -> HBM batch
     std::string err;
     int opt_ecc_slots = 0;        // 0 = auto
@@ -47,10 +48,8 @@ struct stk_ctx {
     int opt_ecc_chunk = 4;
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
-    int opt_ecc_blocks = 1152;    // total workgroups of one ECC iteration launch (all slots): more than the 768 the chip holds at
-                                  // once, so the dispatcher balances the uneven rows-per-wave split (960 / 1344 measure worse)
-    int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = row-factorised Hessian (homography, default), 0 = direct gathers,
-                                  // 1 = LDS-tiled (LDS-DMA), 2 = row-sharing slots; see kernels_ecc.hip
+    int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
+    int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = production (row-factorised Hessian / pipelined affine family), 0 = direct cross-check
     stk_timing timing{};
     hipEvent_t ev[8] = {};
     hipEvent_t poll_ev[2] = {};

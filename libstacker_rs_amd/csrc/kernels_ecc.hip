@@ -514,225 +514,14 @@ __global__ __launch_bounds__(256, 3) void ecc_iter_affine_kernel(EccIterArgs a) 
     block_reduce_store<NS>(acc, a, slot, region);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// row-sharing variant: the waves of a workgroup are the SLOTS. All of them process the same template
-// row at the same time on the same CU, each with its own frame and warp, so the frame-0 taps that
-// the near-identical warps share are fetched once and then hit in that CU's L1 (measured with the
-// direct variant: the fabric-side read traffic equals the algorithmic 16 B/px, i.e. every slot
-// re-fetches frame 0; here it approaches 4 B/px + 12 B/px / n_slots). No LDS, no barrier: a wave
-// reduces its own 66 sums and writes its slot's partial.
-// ---------------------------------------------------------------------------------------------------
-template <int MOTION>
-__global__ __launch_bounds__(512) void ecc_iter_rows_kernel(EccIterArgs a) {
-    constexpr int P = MotionTraits<MOTION>::P;
-    constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
-    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const EccSlot* sl = a.slots + slot;
-    const int frame = sl->frame;
-    if (frame < 0) return;                                    // idle slot: this wave leaves (no barriers below)
-    SlotConst c;
-    load_slot_const(sl, a, c);
-    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
-    float acc[NS];
-#pragma unroll
-    for (int k = 0; k < NS; k++) acc[k] = 0.f;
-    // blocks that share an XCD (blockIdx % 8) take a contiguous band of rows: the frame-0 row shared by
-    // template rows y and y+1 is then an L2 hit for the neighbouring block
-    const int nb = gridDim.x, per = nb >> 3;
-    const int first = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int qw = (a.tw + 3) >> 2;
-    for (int y = first; y < a.th; y += nb) {
-        const float* trow = T + (size_t)y * a.templ_row_stride;
-        for (int qx = lane; qx < qw; qx += 64) {
-            const float4 t4 = *reinterpret_cast<const float4*>(trow + qx * 4);
-#pragma unroll 2
-            for (int j = 0; j < 4; j++) {
-                const int x = qx * 4 + j;
-                const float tvj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
-                if (x < a.tw) pixel_direct<MOTION, NS>(c, a, sl->warp, x, y, tvj, acc);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NS; k++) {
-        float v = acc[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == (k & 63)) a.partials[((size_t)slot * NS + k) * a.nb + blockIdx.x] = (double)v;   // [slot][sum][block]
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// tiled variant: 64 x 16 pixel tiles, source footprint double-buffered in LDS
-// ---------------------------------------------------------------------------------------------------
-constexpr int TILE_W = 64, TILE_H = 16;
-constexpr int REG_W = 72, REG_H = 22;                          // LDS footprint per plane (floats)
-constexpr int REG_N = 3 * REG_W * REG_H;                        // 4752 floats
-constexpr int REG_CHUNKS = REG_N / 4;                           // 16-byte pieces of the footprint (1188)
-constexpr int STAGE_R = (REG_CHUNKS + 255) / 256;               // LDS-DMA instructions per thread for the footprint (5)
-constexpr int REG_PAD_N = STAGE_R * 256 * 4;                    // footprint rounded up to whole wave-instructions (5120 floats)
-constexpr int TBUF_N = TILE_W * TILE_H;                         // template tile, 1024 floats
-constexpr int BUF_FLOATS = REG_PAD_N + TBUF_N;                  // 5888 floats = 23.0 KB per buffer
-
-struct TileInfo { int x0, y0, rx0, ry0; bool fits; };
-
-template <int MOTION>
-__device__ __forceinline__ TileInfo tile_info(const SlotConst& c, int tile, int tiles_x) {
-    TileInfo t;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    t.x0 = tx * TILE_W; t.y0 = ty * TILE_H;
-    // bounding box of the warped tile corners (a projective map with w > 0 keeps the quad convex)
-    // one corner per lane (lane & 3), combined with two butterfly steps: 1 coordinate evaluation instead of 4
-    const int k = threadIdx.x & 3;
-    const float fx = (float)(t.x0 + ((k & 1) ? TILE_W - 1 : 0)), fy = (float)(t.y0 + ((k & 2) ? TILE_H - 1 : 0));
-    float sx, sy, rden, hx, hy;
-    warp_coord<MOTION>(c, fx, fy, sx, sy, rden, hx, hy);
-    bool okl = (__builtin_fabsf(sx) < 1.0e7f) & (__builtin_fabsf(sy) < 1.0e7f);
-    if constexpr (MOTION == STK_MOTION_HOMOGRAPHY) okl &= (rden > 0.0f) & (rden < 1.0e6f);
-    if (!okl) { sx = __builtin_nanf(""); sy = sx; }              // poison: fmin/fmax below would drop a NaN, so track it
-    float bad = okl ? 0.0f : 1.0f;
-    float mnx = sx, mxx = sx, mny = sy, mxy = sy;
-#pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
-        mnx = __builtin_fminf(mnx, __shfl_xor(mnx, o, 64)); mxx = __builtin_fmaxf(mxx, __shfl_xor(mxx, o, 64));
-        mny = __builtin_fminf(mny, __shfl_xor(mny, o, 64)); mxy = __builtin_fmaxf(mxy, __shfl_xor(mxy, o, 64));
-        bad = __builtin_fmaxf(bad, __shfl_xor(bad, o, 64));
-    }
-    const bool ok = __builtin_amdgcn_readfirstlane(bad == 0.0f ? 1 : 0) != 0;
-    if (!ok) { t.rx0 = 0; t.ry0 = 0; t.fits = false; return t; }
-    // origin one texel before the box, rounded down to a multiple of 4 columns (16-byte DMA pieces)
-    const int bx0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mnx)), bx1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mxx));
-    const int by0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mny)), by1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(mxy));
-    t.rx0 = (bx0 - 1) & ~3; t.ry0 = by0 - 1;
-    // taps reach floor(max)+1; keep one more column/row of slack on the far side. The whole footprint
-    // must lie inside the zero-padded plane, because the pieces are copied without clamping.
-    t.fits = (bx1 + 2 - t.rx0 < REG_W) & (by1 + 2 - t.ry0 < REG_H) &
-             (t.rx0 >= -REF_PAD) & (t.rx0 + REG_W <= c.iw + REF_PAD) & (t.ry0 >= -REF_PAD) & (t.ry0 + REG_H <= c.ih + REF_PAD);
-    return t;
-}
-
-template <int MOTION>
-__global__ __launch_bounds__(256) void ecc_iter_tiled_kernel(EccIterArgs a) {
-    constexpr int P = MotionTraits<MOTION>::P;
-    constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF_FLOATS
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = bid >> 3;
-    const int slot = q % a.n_slots;
-    const int region = (q / a.n_slots) * 8 + xcd;
-    const EccSlot* sl = a.slots + slot;
-    const int frame = sl->frame;
-    if (frame < 0) return;
-    SlotConst c;
-    load_slot_const(sl, a, c);
-    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
-    const int tid = threadIdx.x;
-    const int tiles_x = (a.tw + TILE_W - 1) / TILE_W, tiles_y = (a.th + TILE_H - 1) / TILE_H;
-    const int n_tiles = tiles_x * tiles_y;
-    const int rs = a.ref.stride;
-    const size_t plane = (size_t)rs * (a.ref.h + 2 * REF_PAD);
-
-    float acc[NS];
-#pragma unroll
-    for (int k = 0; k < NS; k++) acc[k] = 0.f;
-
-    // Stage one tile into an LDS buffer with LDS-DMA (global_load_lds_dword): each wave instruction
-    // gathers 64 dwords from per-lane global addresses into 64 consecutive LDS dwords, no VGPRs held,
-    // completion counted on vmcnt and drained by the barrier that precedes the buffer's first read.
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // per-thread piece offsets inside a footprint (tile independent): plane * plane_stride + row * rs + 4 * cx
-    int coff[STAGE_R];
-#pragma unroll
-    for (int j = 0; j < STAGE_R; j++) {
-        const int e = min(tid + 256 * j, REG_CHUNKS - 1);           // 16-byte piece; tail lanes land in the pad
-        const int row = e / (REG_W / 4), cx = e - row * (REG_W / 4); // row over all three planes
-        const int p = row / REG_H, ry = row - p * REG_H;
-        coff[j] = p * (int)plane + ry * rs + 4 * cx;
-    }
-    const int toff_t = (tid >> 4) * a.templ_row_stride + 4 * (tid & 15);
-    auto stage_dma = [&](const TileInfo& t, float* buf) {
-        if (t.fits) {
-            const float* g0 = a.ref.I + ((ptrdiff_t)t.ry0 * rs + t.rx0);
-#pragma unroll
-            for (int j = 0; j < STAGE_R; j++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + coff[j]),
-                                                 (__attribute__((address_space(3))) void*)(buf + (wave_u * 64 + 256 * j) * 4), 16, 0, 0);
-        }
-        {   // template tile: 16 rows x 16 pieces, one per thread (rows are 16-byte aligned, stride % 4 == 0)
-            const int rowc = min((tid >> 4), a.th - 1 - t.y0);       // rows below the image repeat the last one (unused)
-            const float* g = T + ((size_t)t.y0 * a.templ_row_stride + t.x0) + (rowc == (tid >> 4) ? toff_t : rowc * a.templ_row_stride + 4 * (tid & 15));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(buf + REG_PAD_N + wave_u * 256), 16, 0, 0);
-        }
-    };
-
-    int tile = region;
-    if (tile < n_tiles) {
-        TileInfo cur = tile_info<MOTION>(c, tile, tiles_x);
-        stage_dma(cur, lds);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int b = 0;
-        while (true) {
-            const int next = tile + a.nb;
-            const bool has_next = next < n_tiles;
-            TileInfo nxt = cur;
-            if (has_next) { nxt = tile_info<MOTION>(c, next, tiles_x); stage_dma(nxt, lds + (b ^ 1) * BUF_FLOATS); }
-            const float* buf = lds + b * BUF_FLOATS;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int ly = (tid >> 6) + 4 * j, lx = tid & 63;
-                const int x = cur.x0 + lx, y = cur.y0 + ly;
-                if (x < a.tw && y < a.th) {
-                    const float tval = buf[REG_PAD_N + ly * TILE_W + lx];
-                    const float fx = (float)x, fy = (float)y;
-                    float sx, sy, rden, hx, hy;
-                    warp_coord<MOTION>(c, fx, fy, sx, sy, rden, hx, hy);
-                    const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
-                    const float ax = sx - flx, ay = sy - fly;
-                    float i00, i01, i10, i11, x00, x01, x10, x11, y00, y01, y10, y11;
-                    if (cur.fits) {
-                        // inside the staged footprint by construction; the clamp only guards NaNs
-                        const int ix = min(max((int)flx - cur.rx0, 0), REG_W - 2);
-                        const int iy = min(max((int)fly - cur.ry0, 0), REG_H - 2);
-                        const float* p = buf + iy * REG_W + ix;
-                        i00 = p[0]; i01 = p[1]; i10 = p[REG_W]; i11 = p[REG_W + 1];
-                        const float* px = p + REG_W * REG_H;
-                        x00 = px[0]; x01 = px[1]; x10 = px[REG_W]; x11 = px[REG_W + 1];
-                        const float* py = px + REG_W * REG_H;
-                        y00 = py[0]; y01 = py[1]; y10 = py[REG_W]; y11 = py[REG_W + 1];
-                    } else {
-                        // footprint too large for LDS (strong rotation / zoom): gather the taps directly
-                        const int ix = (int)__builtin_fminf(__builtin_fmaxf(flx, -2.0f), c.fiw);
-                        const int iy = (int)__builtin_fminf(__builtin_fmaxf(fly, -2.0f), c.fih);
-                        const int off = iy * rs + ix;
-                        const float* p = a.ref.I + off;
-                        i00 = p[0]; i01 = p[1]; i10 = p[rs]; i11 = p[rs + 1];
-                        const float* px = a.ref.gx + off;
-                        x00 = px[0]; x01 = px[1]; x10 = px[rs]; x11 = px[rs + 1];
-                        const float* py = a.ref.gy + off;
-                        y00 = py[0]; y01 = py[1]; y10 = py[rs]; y11 = py[rs + 1];
-                    }
-                    const float Iw = bilerp4(i00, i01, i10, i11, ax, ay);
-                    const float gxw = bilerp4(x00, x01, x10, x11, ax, ay);
-                    const float gyw = bilerp4(y00, y01, y10, y11, ax, ay);
-                    accumulate_pixel<MOTION, NS>(c, sl->warp, x, y, fx, fy, sx, sy, rden, hx, hy, Iw, gxw, gyw, tval, acc);
-                }
-            }
-            if (!has_next) break;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed ...
-            __syncthreads();                                   // ... and so has every other wave's
-            cur = nxt; tile = next; b ^= 1;
-        }
-    }
-    __syncthreads();
-    block_reduce_store<NS>(acc, a, slot, region);
-}
-
+// variant 3: the production kernels (row-factorised homography pass / pipelined affine family); variant 0: the first,
+// direct version (66 per-lane accumulators) — kept as an independent cross-check in the tests and for a caller-supplied
+// initial homography whose m22 is not 1. (Two more variants — LDS-tiled with LDS-DMA, and row-sharing slots — were
+// measured in round 1, never won, and were deleted in round 2.)
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
+    if (grid <= 0) return hipSuccess;
     if (variant == 3) {
-        if (grid <= 0) return hipSuccess;
         switch (motion) {
             case STK_MOTION_HOMOGRAPHY: ecc_iter_h8_kernel<<<grid, 256, 0, s>>>(a); break;
             case STK_MOTION_AFFINE: ecc_iter_affine_kernel<STK_MOTION_AFFINE><<<grid, 256, 0, s>>>(a); break;
@@ -742,35 +531,11 @@ hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStr
         }
         return hipGetLastError();
     }
-    if (variant == 2) {     // one workgroup = n_slots waves; a.nb workgroups in total (multiple of 8)
-        const int threads = 64 * a.n_slots;
-        switch (motion) {
-            case STK_MOTION_HOMOGRAPHY: ecc_iter_rows_kernel<STK_MOTION_HOMOGRAPHY><<<a.nb, threads, 0, s>>>(a); break;
-            case STK_MOTION_AFFINE: ecc_iter_rows_kernel<STK_MOTION_AFFINE><<<a.nb, threads, 0, s>>>(a); break;
-            case STK_MOTION_EUCLIDEAN: ecc_iter_rows_kernel<STK_MOTION_EUCLIDEAN><<<a.nb, threads, 0, s>>>(a); break;
-            case STK_MOTION_TRANSLATION: ecc_iter_rows_kernel<STK_MOTION_TRANSLATION><<<a.nb, threads, 0, s>>>(a); break;
-            default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
-    if (variant == 1) {
-        const size_t lds_bytes = 2 * BUF_FLOATS * sizeof(float);
-        switch (motion) {
-            case STK_MOTION_HOMOGRAPHY: ecc_iter_tiled_kernel<STK_MOTION_HOMOGRAPHY><<<grid, 256, lds_bytes, s>>>(a); break;
-            case STK_MOTION_AFFINE: ecc_iter_tiled_kernel<STK_MOTION_AFFINE><<<grid, 256, lds_bytes, s>>>(a); break;
-            case STK_MOTION_EUCLIDEAN: ecc_iter_tiled_kernel<STK_MOTION_EUCLIDEAN><<<grid, 256, lds_bytes, s>>>(a); break;
-            case STK_MOTION_TRANSLATION: ecc_iter_tiled_kernel<STK_MOTION_TRANSLATION><<<grid, 256, lds_bytes, s>>>(a); break;
-            default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
-    const int gridf = grid;
-    if (gridf <= 0) return hipSuccess;
     switch (motion) {
-        case STK_MOTION_HOMOGRAPHY: ecc_iter_kernel<STK_MOTION_HOMOGRAPHY><<<gridf, 256, 0, s>>>(a); break;
-        case STK_MOTION_AFFINE: ecc_iter_kernel<STK_MOTION_AFFINE><<<gridf, 256, 0, s>>>(a); break;
-        case STK_MOTION_EUCLIDEAN: ecc_iter_kernel<STK_MOTION_EUCLIDEAN><<<gridf, 256, 0, s>>>(a); break;
-        case STK_MOTION_TRANSLATION: ecc_iter_kernel<STK_MOTION_TRANSLATION><<<gridf, 256, 0, s>>>(a); break;
+        case STK_MOTION_HOMOGRAPHY: ecc_iter_kernel<STK_MOTION_HOMOGRAPHY><<<grid, 256, 0, s>>>(a); break;
+        case STK_MOTION_AFFINE: ecc_iter_kernel<STK_MOTION_AFFINE><<<grid, 256, 0, s>>>(a); break;
+        case STK_MOTION_EUCLIDEAN: ecc_iter_kernel<STK_MOTION_EUCLIDEAN><<<grid, 256, 0, s>>>(a); break;
+        case STK_MOTION_TRANSLATION: ecc_iter_kernel<STK_MOTION_TRANSLATION><<<grid, 256, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

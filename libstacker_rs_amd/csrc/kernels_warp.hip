@@ -122,28 +122,50 @@ __global__ __launch_bounds__(256) void warp_accumulate_kernel(WarpArgs a) {
 
 // -----------------------------------------------------------------------------------------------
 // Fast path for the production configuration: BGR u8 source, BORDER_CONSTANT, exact f32 coordinates.
-// Same arithmetic as the generic kernel (bit-identical results), restructured for memory-level
-// parallelism, which is what bounds a gather kernel on HBM:
-//   * the two horizontally adjacent taps of a row are 6 contiguous bytes -> ONE unaligned 8-byte
-//     load (2 loads per pixel and frame instead of 12 byte loads);
-//   * the frame loop is unrolled by WU: all 2*WU loads of a group are issued before the first is
-//     consumed, so every lane keeps 8 HBM/L2 requests in flight;
-//   * the accumulator (12 B/px) is read once and written once per launch, whatever the frame count.
+// Same arithmetic as the generic kernel (bit-identical results). The kernel is bound by VALU issue, not by HBM (3 B
+// of source per pixel and frame against ~60 instructions of coordinate, unpack and lerp arithmetic), so the work of
+// round 2 went into the instruction count:
+//   * X / W and Y / W share ONE v_rcp_f32 + Newton step and then run the exact fma chain the compiler's IEEE division
+//     expands to (q = n r; e = n - d q; q += e r; e = n - d q; q += e r): the same bits as two `/` for a W in the normal
+//     range — which the interior predicate requires — at 8 instructions (3 shared + 5 that pack into v_pk_*) instead of 22;
+//   * whether the 4 taps of ALL frames of the group are inside the frame is voted per wave BEFORE the loads are issued:
+//     interior waves (all but the frame's rim) load from the raw coordinates — no clamps, no end-of-buffer back-off, no
+//     per-tap border selects; rim waves take the general path below with the same coordinates;
+//   * the two horizontally adjacent taps of a row are 6 contiguous bytes -> ONE unaligned 8-byte load, bytes converted
+//     with v_cvt_f32_ubyteN (extract + convert in one instruction);
+//   * the frame loop is unrolled by WU: all 2*WU loads of a group are issued before the first is consumed;
+//   * the accumulator (12 B/px) is read once (if accumulating) and written once per launch, whatever the frame count.
 // -----------------------------------------------------------------------------------------------
-constexpr int WU = 4;
-
-struct TapRow { uint32_t t0, t1; };   // dwords holding B,G,R of the left / right tap in their low 3 bytes
-
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
     uint64_t v;
     __builtin_memcpy(&v, p, 8);
     return v;
 }
 
-template <bool AFFINE>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+
+// n / d for both components, correctly rounded for d and the quotients in the normal range: the compiler's own expansion
+// of an IEEE f32 division without the v_div_scale / v_div_fixup range handling, the reciprocal chain shared by both
+// quotients and the five dependent steps as packed instructions.
+__device__ __forceinline__ f32x2 div2_shared(f32x2 n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    const f32x2 r2 = {r, r}, md = {-d, -d};
+    f32x2 q = n * r2;
+    f32x2 e = pk_fma(md, q, n);
+    q = pk_fma(e, r2, q);
+    e = pk_fma(md, q, n);
+    return pk_fma(e, r2, q);
+}
+
+// WX: waves of a workgroup side by side along x (tile = 64 WX x 4 / WX pixels); WU: frames in flight per lane
+template <bool AFFINE, int WX, int WU>
 __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int x = (blockIdx.x * WX + (wave % WX)) * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * (4 / WX) + wave / WX;
     if (x >= a.dw || y >= a.dh) return;
     float* accp = a.acc + (size_t)y * a.acc_stride + (size_t)x * 3;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -153,48 +175,61 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
     const int stride32 = (int)a.src_stride;
     const float alpha = a.alpha, b0 = a.bv[0], b1 = a.bv[1], b2 = a.bv[2];
 
-    for (int f0 = 0; f0 < a.n_frames; f0 += WU) {
-        uint64_t raw0[WU], raw1[WU];
-        float ax[WU], ay[WU];
-        int ox[WU];            // ix - xb: 0 normal, -1 left tap outside, 1 right tap outside, else both outside
-        bool vy0[WU], vy1[WU];
-        int sh0[WU], sh1[WU];  // right-shift (bits) that undoes the end-of-buffer back-off
-        bool interior = true;
-#pragma unroll
-        for (int u = 0; u < WU; u++) {
-            const int f = min(f0 + u, a.n_frames - 1);
-            const WarpFrame* fr = a.frames + f;
-            const uint8_t* __restrict__ src = (const uint8_t*)fr->src;
-            float X = __builtin_fmaf(fr->M[0], fx, __builtin_fmaf(fr->M[1], fy, fr->M[2]));
-            float Y = __builtin_fmaf(fr->M[3], fx, __builtin_fmaf(fr->M[4], fy, fr->M[5]));
-            if (!AFFINE) {
-                const float W = __builtin_fmaf(fr->M[6], fx, __builtin_fmaf(fr->M[7], fy, fr->M[8]));
-                X = X / W; Y = Y / W;
-            }
-            const bool finite = (__builtin_fabsf(X) < 1e9f) & (__builtin_fabsf(Y) < 1e9f);
-            const float flx = __builtin_floorf(X), fly = __builtin_floorf(Y);
-            const int ix = finite ? (int)flx : -100000, iy = finite ? (int)fly : -100000;
-            ax[u] = finite ? X - flx : 0.0f; ay[u] = finite ? Y - fly : 0.0f;
-            const int xb = min(max(ix, 0), sw - 2);
-            ox[u] = ix - xb;
-            vy0[u] = (unsigned)iy < (unsigned)sh; vy1[u] = (unsigned)(iy + 1) < (unsigned)sh;
-            const int yb0 = min(max(iy, 0), sh - 1), yb1 = min(max(iy + 1, 0), sh - 1);
-            // an 8-byte load at the last pixel pair of the last row would run 2 bytes past the frame
-            const int back0 = (yb0 == sh - 1 && xb == sw - 2) ? 2 : 0;
-            const int back1 = (yb1 == sh - 1 && xb == sw - 2) ? 2 : 0;
-            sh0[u] = back0 * 8; sh1[u] = back1 * 8;
-            // one frame is < 4 GiB (checked by the launcher): 32-bit offsets on the frame's uniform base pointer
-            raw0[u] = load_u64_unaligned(src + (unsigned)(yb0 * stride32 + xb * 3 - back0));
-            raw1[u] = load_u64_unaligned(src + (unsigned)(yb1 * stride32 + xb * 3 - back1));
-            // all four taps inside the frame and no end-of-buffer back-off: the common case, decided per wave below
-            interior &= (ix == xb) & ((unsigned)iy < (unsigned)(sh - 1)) & ((back0 | back1) == 0);
-        }
 #define STK_CH(d, sft) ((float)(((d) >> (sft)) & 0xffu) * alpha)
 #define STK_LERP(p00, p01, p10, p11)                                                   \
     __builtin_fmaf(ay[u], __builtin_fmaf(ax[u], (p11) - (p10), (p10)) - __builtin_fmaf(ax[u], (p01) - (p00), (p00)), \
                    __builtin_fmaf(ax[u], (p01) - (p00), (p00)))
+    for (int f0 = 0; f0 < a.n_frames; f0 += WU) {
+        float ax[WU], ay[WU], Xs[WU], Ys[WU];
+        int ix[WU], iy[WU];
+        bool interior = true;
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const WarpFrame* fr = a.frames + min(f0 + u, a.n_frames - 1);
+            // (X, Y) as one packed pair: fma(M0, x, fma(M1, y, M2)) and fma(M3, x, fma(M4, y, M5)) — the generic kernel's operations
+            bool fin = true;                              // false: X or Y is NaN / inf / absurdly large
+            f32x2 XY = pk_fma(f32x2{fr->M[0], fr->M[3]}, f32x2{fx, fx}, pk_fma(f32x2{fr->M[1], fr->M[4]}, f32x2{fy, fy}, f32x2{fr->M[2], fr->M[5]}));
+            if (!AFFINE) {
+                const float W = __builtin_fmaf(fr->M[6], fx, __builtin_fmaf(fr->M[7], fy, fr->M[8]));
+                // |W| in [2^-40, 2^40] (it is ~1 for any real homography) and |X|, |Y| < 2^40: the range in which the IEEE
+                // expansion applies no scaling, so the shared chain returns the same bits
+                const float aw = __builtin_fabsf(W);
+                const bool safe = (__builtin_fmaxf(__builtin_fmaxf(aw, __builtin_fabsf(XY.x)), __builtin_fabsf(XY.y)) < 1.0995116e12f) &
+                                  (aw > 9.094947e-13f);
+                if (__all(safe)) XY = div2_shared(XY, W);       // finite operands in range: finite quotients
+                else {
+                    XY.x = XY.x / W; XY.y = XY.y / W;
+                    fin = (__builtin_fabsf(XY.x) < 1e9f) & (__builtin_fabsf(XY.y) < 1e9f);
+                }
+            } else {
+                fin = (__builtin_fabsf(XY.x) < 1e9f) & (__builtin_fabsf(XY.y) < 1e9f);
+            }
+            const float X = XY.x, Y = XY.y;
+            Xs[u] = X; Ys[u] = Y;
+            const f32x2 fl = {__builtin_floorf(X), __builtin_floorf(Y)};
+            ix[u] = (int)fl.x; iy[u] = (int)fl.y;         // saturating conversion; NaN -> 0, caught by the finite test
+            const f32x2 fr2 = XY - fl;
+            ax[u] = fr2.x; ay[u] = fr2.y;
+            // all four taps inside the frame with a row to spare below (the 8-byte load of the last pixel pair of the last
+            // row would run 2 bytes past the frame; rows sh-2 and sh-1 are left to the rim path). The int conversion saturates,
+            // so huge coordinates fail the unsigned tests by themselves.
+            interior &= fin & ((unsigned)ix[u] < (unsigned)(sw - 1)) & ((unsigned)iy[u] < (unsigned)(sh - 2));
+        }
         if (__all(interior)) {
-            // every lane of the wave has all taps of all WU frames inside: same arithmetic without the border selects
+            uint64_t raw0[WU], raw1[WU];
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                const uint8_t* __restrict__ src = (const uint8_t*)a.frames[min(f0 + u, a.n_frames - 1)].src;
+                // one frame is < 2 GiB (checked by the launcher): 32-bit offsets on the frame's uniform base pointer
+                unsigned o = (unsigned)(__mul24(iy[u], stride32) + ix[u] * 3);      // rows < 2^24, row stride < 2^24 bytes
+#ifdef STK_WARP_ABLATE
+                if (a.tune & 0x100) o &= ~7u;                                         // ablation: aligned gathers (wrong pixels)
+                if (a.tune & 0x200) { raw0[u] = o; raw1[u] = o + 1; continue; }       // ablation: no loads at all
+                if (a.tune & 0x400) { raw0[u] = *(const uint32_t*)(src + (o & ~3u)); raw1[u] = *(const uint32_t*)(src + ((o + stride32) & ~3u)); continue; }
+#endif
+                raw0[u] = load_u64_unaligned(src + o);
+                raw1[u] = load_u64_unaligned(src + o + (unsigned)stride32);
+            }
 #pragma unroll
             for (int u = 0; u < WU; u++) {
                 if (f0 + u < a.n_frames) {
@@ -207,18 +242,31 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
             }
             continue;
         }
+        // rim waves: clamped loads, per-tap border selects
 #pragma unroll
         for (int u = 0; u < WU; u++) {
             if (f0 + u < a.n_frames) {
-                const uint64_t r0 = raw0[u] >> sh0[u], r1 = raw1[u] >> sh1[u];
+                const uint8_t* __restrict__ src = (const uint8_t*)a.frames[f0 + u].src;
+                const bool finite = (__builtin_fabsf(Xs[u]) < 1e9f) & (__builtin_fabsf(Ys[u]) < 1e9f);   // false for NaN / inf
+                const int jx = finite ? ix[u] : -100000, jy = finite ? iy[u] : -100000;
+                if (!finite) { ax[u] = 0.0f; ay[u] = 0.0f; }
+                const int xb = min(max(jx, 0), sw - 2);
+                const int ox = jx - xb;            // 0 normal, -1 left tap outside, 1 right tap outside, else both outside
+                const bool vy0 = (unsigned)jy < (unsigned)sh, vy1 = (unsigned)(jy + 1) < (unsigned)sh;
+                const int yb0 = min(max(jy, 0), sh - 1), yb1 = min(max(jy + 1, 0), sh - 1);
+                // an 8-byte load at the last pixel pair of the last row would run 2 bytes past the frame: back off, shift
+                const int back0 = (yb0 == sh - 1 && xb == sw - 2) ? 2 : 0;
+                const int back1 = (yb1 == sh - 1 && xb == sw - 2) ? 2 : 0;
+                const uint64_t r0 = load_u64_unaligned(src + (unsigned)(yb0 * stride32 + xb * 3 - back0)) >> (back0 * 8);
+                const uint64_t r1 = load_u64_unaligned(src + (unsigned)(yb1 * stride32 + xb * 3 - back1)) >> (back1 * 8);
                 // left tap = bytes 0..2, right tap = bytes 3..5 of the pair starting at column xb
                 const uint32_t a0 = (uint32_t)r0, a1 = (uint32_t)(r0 >> 24);
                 const uint32_t c0 = (uint32_t)r1, c1 = (uint32_t)(r1 >> 24);
                 // which dword serves tap x0 = ix and tap x1 = ix+1 (column offset from xb: ox, ox+1)
-                const bool l_ok = (ox[u] == 0) | (ox[u] == 1), r_ok = (ox[u] == 0) | (ox[u] == -1);
-                const uint32_t tl0 = ox[u] == 0 ? a0 : a1, tr0 = ox[u] == 0 ? a1 : a0;
-                const uint32_t tl1 = ox[u] == 0 ? c0 : c1, tr1 = ox[u] == 0 ? c1 : c0;
-                const bool v00 = l_ok & vy0[u], v01 = r_ok & vy0[u], v10 = l_ok & vy1[u], v11 = r_ok & vy1[u];
+                const bool l_ok = (ox == 0) | (ox == 1), r_ok = (ox == 0) | (ox == -1);
+                const uint32_t tl0 = ox == 0 ? a0 : a1, tr0 = ox == 0 ? a1 : a0;
+                const uint32_t tl1 = ox == 0 ? c0 : c1, tr1 = ox == 0 ? c1 : c0;
+                const bool v00 = l_ok & vy0, v01 = r_ok & vy0, v10 = l_ok & vy1, v11 = r_ok & vy1;
                 {
                     const float p00 = v00 ? STK_CH(tl0, 0) : b0, p01 = v01 ? STK_CH(tr0, 0) : b0;
                     const float p10 = v10 ? STK_CH(tl1, 0) : b0, p11 = v11 ? STK_CH(tr1, 0) : b0;
@@ -236,9 +284,9 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
                 }
             }
         }
+    }
 #undef STK_CH
 #undef STK_LERP
-    }
     accp[0] = s0; accp[1] = s1; accp[2] = s2;
 }
 
@@ -255,6 +303,7 @@ __device__ __forceinline__ Tap12 load_tap12(const uint8_t* p) {
 
 template <bool AFFINE>
 __global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) {
+    constexpr int WU = 4;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.dw || y >= a.dh) return;
@@ -340,9 +389,25 @@ __global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) 
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
     dim3 grid((a.dw + 63) / 64, (a.dh + 3) / 4);
     if (depth == 8 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 &&
-        (size_t)a.sw * a.sh * 3 >= 16 && a.src_stride * (size_t)a.sh < ((size_t)1 << 31)) {
-        if (a.is_affine) warp_accumulate_u8c3_kernel<true><<<grid, 256, 0, s>>>(a);
-        else warp_accumulate_u8c3_kernel<false><<<grid, 256, 0, s>>>(a);
+        (size_t)a.sw * a.sh * 3 >= 16 && a.src_stride * (size_t)a.sh < ((size_t)1 << 31) && a.src_stride < (1u << 23) && a.sh < (1 << 23)) {
+        const int v = a.tune;                       // tuning: bits 0-1 tile shape, bits 4-5 frames in flight
+#define STK_U8C3(WX, WU)                                                                                   \
+        do {                                                                                               \
+            dim3 g((a.dw + 64 * WX - 1) / (64 * WX), (a.dh + 4 / WX - 1) / (4 / WX));                      \
+            if (a.is_affine) warp_accumulate_u8c3_kernel<true, WX, WU><<<g, 256, 0, s>>>(a);              \
+            else warp_accumulate_u8c3_kernel<false, WX, WU><<<g, 256, 0, s>>>(a);                         \
+        } while (0)
+        switch (v) {
+            case 0x01: STK_U8C3(2, 4); break;
+            case 0x02: STK_U8C3(4, 4); break;
+            case 0x10: STK_U8C3(1, 8); break;
+            case 0x11: STK_U8C3(2, 8); break;
+            case 0x12: STK_U8C3(4, 8); break;
+            case 0x20: STK_U8C3(1, 2); break;
+            case 0x22: STK_U8C3(4, 2); break;
+            default: STK_U8C3(1, 4); break;
+        }
+#undef STK_U8C3
         return hipGetLastError();
     }
     if (depth == 16 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 && a.sh >= 2 &&

@@ -153,11 +153,12 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
-    else if (n == "ecc_variant") { if (value < 0 || value > 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 0..3"); ctx->opt_ecc_variant = (int)value; }
+    else if (n == "ecc_variant") { if (value != 0 && value != 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 3 (production) or 0 (direct cross-check)"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
+    else if (n == "warp_tune") ctx->opt_warp_tune = (int)value;
     else if (n == "upload_batch") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "upload_batch out of range"); ctx->opt_upload_batch = (int)value; }
-    else if (n == "ecc_blocks") { if (value < 8 || value > 65536) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
+    else if (n == "ecc_blocks") { if (value != 0 && (value < 8 || value > 65536)) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
     return STK_OK;
 }
@@ -201,29 +202,21 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     pl.ref_plane_floats = (size_t)pl.ref_stride * (h + 2 * REF_PAD);
     const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
     pl.nsums = ecc_nsums(P);
-    int slots = ctx->opt_ecc_slots;
-    if (slots <= 0) {
-        const double px = (double)w * h;
-        slots = (int)std::lround(4.0 * 8294400.0 / px);
-        slots = std::max(4, std::min(slots, 16));
-    }
+    // Frames in flight per launch ("slots"): up to 32. Every (iterate, solve) launch pair costs ~20 us of solve latency
+    // and launch gaps whatever it carries, so the more frames share it the better: 4 -> 32 slots is +13 % at 256 4K frames
+    // and +12 % at 32 (all moving frames of a 32-frame shard then iterate in lockstep, no queue refill at all).
+    // Workgroups per frame: a FIXED 288 (the 1152 per 4 frames tuned in round 1), as many as the frame has 4-row groups if
+    // fewer. Fixed means that a frame's f32 summation partition depends on nothing but the frame size: its warp is
+    // bit-identical however the stack is sharded over GPUs and however many frames happen to share the launch.
+    int slots = ctx->opt_ecc_slots > 0 ? ctx->opt_ecc_slots : 32;
     pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
-    slots = pl.n_slots;
-    // blocks per slot: multiple of 8 (XCD-aware decode), each block = 4 waves = 4 rows per sweep
-    // work units of one slot: 4-row groups (direct variant) or 64x16 tiles (tiled variant)
-    const int units = ctx->opt_ecc_variant == 1 ? ((w + ECC_TILE_W - 1) / ECC_TILE_W) * ((h + ECC_TILE_H - 1) / ECC_TILE_H) : (h + 3) / 4;
-    int nb = std::max(8, std::min(units, ctx->opt_ecc_blocks / slots));
-    if (ctx->opt_ecc_variant == 2) {
-        // row-sharing variant: a workgroup = n_slots waves (one per slot) on one template row; as many
-        // workgroups as keep the same number of waves in flight as the other variants
-        pl.n_slots = std::min(pl.n_slots, 8);
-        nb = std::max(8, std::min(h, ctx->opt_ecc_blocks * 4 / pl.n_slots));
-    }
-    nb = std::max(8, (nb / 8) * 8);
+    const int units = (h + 3) / 4;                           // work units of one frame: 4-row groups (one row per wave per sweep)
+    int nb = ctx->opt_ecc_blocks > 0 ? ctx->opt_ecc_blocks / pl.n_slots : 288;
+    nb = std::max(8, std::min(units, nb));
+    nb = std::max(8, (nb / 8) * 8);                          // multiple of 8: XCD-aware block decode
     pl.nb = nb;
     HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 5 * sizeof(float)));
     HIP_TRY(ctx->blur_tmp.reserve(pl.templ_plane_stride * sizeof(float)));
-    // + slack: the tiled kernel copies whole 64-float tile rows, which may run past the last row's end
     HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1) + 1024));
     HIP_TRY(ctx->slots.reserve(sizeof(EccSlot) * pl.n_slots));
     HIP_TRY(ctx->queue.reserve(sizeof(EccQueue)));
@@ -380,7 +373,7 @@ stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int depth, 
     a.border_mode = border_mode;
     for (int c = 0; c < 4; c++) a.bv[c] = border_value ? (float)border_value[c] : 0.f;
     a.acc = acc; a.dw = w; a.dh = h; a.acc_stride = acc_stride_floats;
-    a.accumulate = accumulate; a.is_affine = is_affine; a.subpixel_bits = ctx->opt_subpixel_bits;
+    a.accumulate = accumulate; a.is_affine = is_affine; a.subpixel_bits = ctx->opt_subpixel_bits; a.tune = ctx->opt_warp_tune;
     HIP_TRY(launch_warp_accumulate(a, depth, ctx->stream));
     // the host vector may die before the copy above ran if the caller does not synchronise
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -764,10 +757,13 @@ stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* i
     EccPlan pl{};
     // variant 3 assumes m22 == 1 (true for every warp findTransformECC itself produces); a caller-supplied
     // initial warp with another m22 takes the general kernel
-    const int saved_variant = ctx->opt_ecc_variant;
-    if (saved_variant == 3 && params->motion_type == STK_MOTION_HOMOGRAPHY && warp[8] != 1.0f) ctx->opt_ecc_variant = 0;
+    struct VariantGuard {                                   // restores the option on every exit path
+        stk_ctx* c; int saved;
+        ~VariantGuard() { c->opt_ecc_variant = saved; }
+    } guard{ctx, ctx->opt_ecc_variant};
+    if (guard.saved == 3 && params->motion_type == STK_MOTION_HOMOGRAPHY && warp[8] != 1.0f) ctx->opt_ecc_variant = 0;
     st = ecc_plan(ctx, width, height, 1, params->motion_type, pl);
-    if (st) { ctx->opt_ecc_variant = saved_variant; return st; }
+    if (st) return st;
     const size_t rb = (size_t)width * (depth / 8);
     if ((st = ecc_prepare_reference(ctx, pl, in, depth, 1, rb, params->gauss_filt_size))) return st;
     HIP_TRY(launch_grey_blur(t, depth, 1, width, height, rb, params->gauss_filt_size, ctx->templates.as<float>(), pl.templ_row_stride, ctx->stream));
@@ -779,7 +775,6 @@ stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* i
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<EccFrameResult> res;
     st = ecc_run(ctx, pl, crit, ctx->init_warps.as<float>(), res);
-    ctx->opt_ecc_variant = saved_variant;
     if (st) return st;
     if (crit.n_iter >= 1) for (int k = 0; k < 9; k++) warp[k] = res[0].warp[k];
     if (rho) *rho = res[0].rho;

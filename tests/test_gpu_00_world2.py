@@ -26,4 +26,4 @@ def test_two_ranks_through_the_shard_entry_points(tmp_path):
     assert v["dropped"] == 1 and v["single_dropped"] == 1 and v["added"] == 8          # n - dropped, summed over ranks
     assert v["kp_per_frame_equal"]                         # every frame's status and H, bit for bit
     assert v["kp_max_abs"] <= 1e-6                         # image: only the order of the f32 adds differs
-    assert v["ecc_added"] == 8 and v["ecc_max_abs"] <= 1e-5   # 4-frame ranges < 16 ECC slots: per-frame round-off
+    assert v["ecc_added"] == 8 and v["ecc_max_abs"] <= 1e-6   # per-frame warps identical for any split (fixed workgroup partition)

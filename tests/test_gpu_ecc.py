@@ -119,32 +119,30 @@ def test_ecc_match_device_resident_equals_host_fed(stacker, small_stack):
     assert np.array_equal(dev.cpu().numpy(), host)              # deterministic: fixed reduction order
 
 
-def test_tiled_lds_variant_agrees_with_direct(stacker, small_stack):
-    # same per-pixel arithmetic, different pixel -> lane assignment: only the f32 summation order differs
+def test_direct_variant_agrees_with_production(stacker, small_stack):
+    # same per-pixel arithmetic, different accumulation structure (66 per-lane sums vs row-factorised moments): an
+    # independent cross-check of the production kernel; only the f32 summation order differs
     frames, _ = small_stack
     base, s0 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
-    stacker.set_option("ecc_variant", 1)
+    stacker.set_option("ecc_variant", 0)
     try:
-        out, s1 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
-        # a 1.25x zoom about the centre: the 64-px tile footprint (80 px) does not fit the LDS buffer -> gather path
-        big = np.array([[1.25, 0, -40.0], [0, 1.25, -30.0], [0, 0, 1.0]], np.float32)
-        g0 = oracle.grey(frames[0])
-        p1 = EccMatchParameters(MotionType.Homography, 1, None, 5)
-        Wt, rho_t, _ = stacker.find_transform_ecc(g0, g0, big, p1)
-        stacker.set_option("ecc_variant", 2)       # row-sharing variant: waves of a workgroup = slots
-        out2, s2 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
-        stacker.set_option("ecc_variant", 0)       # direct gathers, 66 per-lane accumulators
         out0, s3 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
     finally:
-        stacker.set_option("ecc_variant", 3)       # default: row-factorised Hessian
-    Wd, rho_d, _ = stacker.find_transform_ecc(g0, g0, big, p1)
-    for a, b, c, d in zip(s0[1:], s1[1:], s2[1:], s3[1:]):
-        assert abs(a["iterations"] - b["iterations"]) <= 1 and abs(a["iterations"] - c["iterations"]) <= 1
+        stacker.set_option("ecc_variant", 3)
+    for a, d in zip(s0[1:], s3[1:]):
         assert abs(a["iterations"] - d["iterations"]) <= 1
-        assert synth.corner_error(a["warp"], b["warp"], 320, 240) <= 0.02
-        assert synth.corner_error(a["warp"], c["warp"], 320, 240) <= 0.02
         assert synth.corner_error(a["warp"], d["warp"], 320, 240) <= 0.02
-    assert abs(rho_t - rho_d) <= 1e-6 and np.allclose(Wt, Wd, rtol=0, atol=1e-4)
+    # a caller-supplied start whose m22 is not 1 takes the direct kernel and must leave the option as it was
+    g0 = oracle.grey(frames[0])
+    big = np.array([[1.25, 0, -40.0], [0, 1.25, -30.0], [0, 0, 1.0]], np.float32)
+    p1 = EccMatchParameters(MotionType.Homography, 1, None, 5)
+    Wd, rho_d, _ = stacker.find_transform_ecc(g0, g0, big, p1)
+    Ws, rho_s, _ = stacker.find_transform_ecc(g0, g0, big * np.float32(2.0), p1)     # the same map, scaled: m22 = 2
+    assert abs(rho_s - rho_d) <= 1e-5
+    out1, s1 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
+    assert np.array_equal(out1, base)                                                  # variant restored: same bits as before
+    with pytest.raises(Exception):
+        stacker.set_option("ecc_variant", 1)                                           # deleted in round 2
 
 
 def test_slot_count_does_not_change_results(stacker, small_stack):

@@ -69,9 +69,8 @@ def test_ecc_4k_ground_truth_oracle_and_determinism(stacker, stack4k):
 
 
 def test_ecc_4k_shard_invariance(stacker, stack4k):
-    # 8 moving frames over 2 ranks = 4 each = the slot count at 4K: every frame is summed over the same workgroup
-    # partition as in the single-GPU run, so its warp is bit-identical. (A shard with FEWER moving frames than slots
-    # spreads each frame over more workgroups and differs at f32 round-off, ~1e-7: DESIGN.md section 4.)
+    # 8 moving frames over 2 ranks: every frame is summed over its fixed workgroup partition (288 per 4K frame), so its
+    # warp is bit-identical to the single-GPU run for any split.
     frames, _ = stack4k
     n = frames.shape[0]
     full, full_stats = stacker.ecc_match(frames, ECC, return_stats=True)
@@ -150,9 +149,9 @@ def test_config0_nine_800x600_frames_keypoint_match(stacker):
 
 
 def test_ecc_1080p_sixteen_slot_plan(stacker):
-    # BASELINE configs[2]'s shape: 1920x1080, ecc_match Homography / 5000 / 1e-5 / gauss 5. At 1080p the engine iterates
-    # 16 frames per launch: 33 frames = 32 moving = two full slot generations (the device queue refills every slot once)
-    # and, split over 2 ranks, 16 moving frames each = the same workgroup partition per frame as the unsharded run.
+    # BASELINE configs[2]'s shape: 1920x1080, ecc_match Homography / 5000 / 1e-5 / gauss 5. 33 frames = 32 moving frames:
+    # all in flight at once by default (32 slots); with ecc_slots = 5 the device queue refills slots six times over. Either
+    # way, and split over 2 ranks, every frame keeps its own fixed workgroup partition: identical bits.
     frames, G = synth.make_stack(33, 1920, 1080, device="cuda")
     n = frames.shape[0]
     out, stats = stacker.ecc_match(frames, ECC, return_stats=True)
@@ -185,6 +184,12 @@ def test_ecc_1080p_sixteen_slot_plan(stacker):
         total += acc
     assert float((stacker.finalize_mean(total, n) - out).abs().max()) <= 1e-6
     assert torch.equal(out, stacker.ecc_match(frames, ECC))                                 # same input, same bits
+    stacker.set_option("ecc_slots", 5)                                                      # queue refill path: 32 frames through 5 slots
+    try:
+        out5, st5 = stacker.ecc_match(frames, ECC, return_stats=True)
+    finally:
+        stacker.set_option("ecc_slots", 0)
+    assert torch.equal(out5, out) and all(np.array_equal(a["warp"], b["warp"]) for a, b in zip(st5, stats))
 
 
 def test_hybrid_4k_16bit(stacker):

@@ -26,8 +26,8 @@ def test_rccl_selftest(stacker, multi):
 
 
 def test_multi_ecc_equals_single(stacker, multi):
-    # 33 frames of 320x240: 32 moving = 16 per member = the ECC slot count at this size, so each frame is summed over the
-    # same workgroup partition as in the single-device run and its warp is bit-identical
+    # every frame is summed over a fixed workgroup partition (ecc_plan), whatever shares the launch with it: its warp is
+    # bit-identical to the single-device run for any split of the stack
     frames, _ = synth.make_stack(33, 320, 240)
     fr = list(frames.numpy())
     one, s1 = stacker.ecc_match(fr, ECC, return_stats=True)
@@ -52,7 +52,7 @@ def test_multi_keypoint_and_hybrid_equal_single(stacker, multi):
     good = [f for i, f in enumerate(fr) if i != 3]
     h1 = stacker.hybrid_match(good, KP, EccMatchParameters(MotionType.Homography, 200, 1e-5, 5))
     h2 = multi.hybrid_match(good, KP, EccMatchParameters(MotionType.Homography, 200, 1e-5, 5))
-    assert np.max(np.abs(h1 - h2)) <= 1e-5               # 2-3 frames per member < ECC slots: per-frame round-off
+    assert np.max(np.abs(h1 - h2)) <= 1e-6               # per-frame results identical; the order of the f32 adds differs
 
 
 def test_multi_more_devices_than_frames_and_errors(stacker, multi):

@@ -160,3 +160,33 @@ def test_warp_degenerate_matrix_gives_border(stacker):
     got = stacker.warp_accumulate(img, np.zeros((3, 3)))       # singular: inverse is the zero matrix
     ref = oracle.warp_frame(img, np.zeros((3, 3)))
     assert np.array_equal(got, ref) and not np.isnan(got).any()
+
+
+def test_warp_u8_fast_path_is_bit_identical_to_the_generic_kernel(stacker):
+    """warp_accumulate_u8c3_kernel shares one reciprocal chain between X / W and Y / W (the compiler's own IEEE expansion
+    without the range scaling) and skips clamps and border selects on interior waves: wherever all four taps are inside
+    the frame it must return the very bits of the generic kernel (true `/`, per-tap selects), which BORDER_REPLICATE selects."""
+    rng = np.random.default_rng(3)
+    h, w = 333, 517                                             # not a multiple of the 64 x 4 tile
+    frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ones = np.full((h, w, 3), 255, np.uint8)
+    from libstacker_rs_amd import synth
+    mats = [np.eye(3), synth.random_homography(rng, w, h, 8.0), synth.random_homography(rng, w, h, 30.0),
+            np.array([[0.7, 0.2, 15.3], [-0.25, 0.9, 40.1], [4e-4, -3e-4, 1.0]]),          # strong perspective: W far from 1
+            np.array([[1e-3, 0, 0], [0, 1e-3, 0], [0, 0, 1e-3]]),                            # tiny W (still in the safe range)
+            np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1e-20]])]                                 # |1 / W| = 1e20: leaves the shared chain for `/`
+    for M in mats:
+        fast = stacker.warp_accumulate(frame, M)
+        slow = stacker.warp_accumulate(frame, M, border_mode=1)
+        cov = stacker.warp_accumulate(ones, M)
+        inside = (cov == np.float32(255) * np.float32(1.0 / 255.0)).all(axis=2)
+        assert np.array_equal(fast[inside], slow[inside])
+        assert inside.mean() > 0.5 or abs(np.linalg.det(M)) < 1e-6 or M[2, 2] < 1e-6
+        # and an accumulating second pass over several frames (the unrolled frame loop, odd tail)
+    acc = stacker.warp_accumulate(frame, mats[1])
+    accg = stacker.warp_accumulate(frame, mats[1], border_mode=1)
+    cov = stacker.warp_accumulate(ones, mats[1])
+    inside = (cov == 1.0).all(axis=2)
+    acc2 = stacker.warp_accumulate(frame, mats[1], acc=acc.copy())
+    accg2 = stacker.warp_accumulate(frame, mats[1], border_mode=1, acc=accg.copy())
+    assert np.array_equal(acc2[inside], accg2[inside])
