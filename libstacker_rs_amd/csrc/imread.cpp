@@ -8,7 +8,9 @@
 // grey / RGB TIFF goes through libtiff's handle-based API (TIFFOpen / TIFFGetField / TIFFReadScanline), loaded the same way. A file that is missing or not an image behaves as in the reference: imread gives an
 // empty Mat and the following cvtColor raises -> STK_BACKEND_ERROR (OpenCvError).
 #include <dlfcn.h>
+#include <setjmp.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -198,6 +200,174 @@ int tiff_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
     return 0;
 }
 
+
+// ---- JPEG through libjpeg-turbo's classic API (libjpeg.so.8), resolved at run time --------------------------------------
+// The reference's own data set is JPEG (README.md:18, examples/main.rs:35) and OpenCV decodes it with this very library
+// family at its default settings (JDCT_ISLOW, fancy upsampling), which is what is requested here, so the pixels are
+// OpenCV's. The image ships the library but not jpeglib.h: the leading part of jpeg_decompress_struct (stable since
+// libjpeg 6b) and jpeg_error_mgr are declared below, and nothing is taken on trust —
+//   * the struct size comes from the library itself: jpeg_CreateDecompress is first called with a guess, and on a mismatch
+//     the library's error (JERR_BAD_STRUCT_SIZE) carries the size it expects;
+//   * the field offsets are checked against an independent parse of the file's SOF marker (width, height, components)
+//     after jpeg_read_header, and output_scanline must advance exactly as rows are delivered;
+//   * any disagreement ends in STK_NOT_IMPLEMENTED ("decode on the caller's side"), never in a wrong image.
+struct JpegErrorMgr {                       // struct jpeg_error_mgr
+    void (*error_exit)(void*);
+    void (*emit_message)(void*, int);
+    void (*output_message)(void*);
+    void (*format_message)(void*, char*);
+    void (*reset_error_mgr)(void*);
+    int msg_code;
+    union { int i[8]; char s[80]; } msg_parm;
+    int trace_level;
+    long num_warnings;
+    const char* const* jpeg_message_table;
+    int last_jpeg_message;
+    const char* const* addon_message_table;
+    int first_addon_message, last_addon_message;
+    char slack[128];                        // room for a larger library-side struct
+};
+struct JpegDecompressHead {                 // the leading fields of struct jpeg_decompress_struct (x86-64 layout)
+    JpegErrorMgr* err; void* mem; void* progress; void* client_data;
+    int is_decompressor, global_state;
+    void* src;
+    unsigned image_width, image_height;
+    int num_components, jpeg_color_space, out_color_space;
+    unsigned scale_num, scale_denom;
+    double output_gamma;
+    int buffered_image, raw_data_out, dct_method, do_fancy_upsampling, do_block_smoothing, quantize_colors, dither_mode,
+        two_pass_quantize, desired_number_of_colors, enable_1pass_quant, enable_external_quant, enable_2pass_quant;
+    unsigned output_width, output_height;
+    int out_color_components, output_components, rec_outbuf_height, actual_number_of_colors;
+    void* colormap;
+    unsigned output_scanline;
+};
+static_assert(offsetof(JpegDecompressHead, image_width) == 48 && offsetof(JpegDecompressHead, output_gamma) == 80 &&
+              offsetof(JpegDecompressHead, output_width) == 136 && offsetof(JpegDecompressHead, output_scanline) == 168, "jpeglib.h layout");
+
+struct JpegApi {
+    JpegErrorMgr* (*std_error)(JpegErrorMgr*) = nullptr;
+    void (*create)(void*, int version, size_t structsize) = nullptr;
+    void (*mem_src)(void*, const unsigned char*, unsigned long) = nullptr;
+    int (*read_header)(void*, int require_image) = nullptr;
+    int (*start)(void*) = nullptr;
+    unsigned (*read_scanlines)(void*, unsigned char**, unsigned) = nullptr;
+    int (*finish)(void*) = nullptr;
+    void (*destroy)(void*) = nullptr;
+    bool ok = false;
+};
+const JpegApi& jpeg_api() {
+    static const JpegApi api = []() {
+        JpegApi a;
+        void* h = dlopen("libjpeg.so.8", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.std_error = reinterpret_cast<decltype(a.std_error)>(dlsym(h, "jpeg_std_error"));
+        a.create = reinterpret_cast<decltype(a.create)>(dlsym(h, "jpeg_CreateDecompress"));
+        a.mem_src = reinterpret_cast<decltype(a.mem_src)>(dlsym(h, "jpeg_mem_src"));
+        a.read_header = reinterpret_cast<decltype(a.read_header)>(dlsym(h, "jpeg_read_header"));
+        a.start = reinterpret_cast<decltype(a.start)>(dlsym(h, "jpeg_start_decompress"));
+        a.read_scanlines = reinterpret_cast<decltype(a.read_scanlines)>(dlsym(h, "jpeg_read_scanlines"));
+        a.finish = reinterpret_cast<decltype(a.finish)>(dlsym(h, "jpeg_finish_decompress"));
+        a.destroy = reinterpret_cast<decltype(a.destroy)>(dlsym(h, "jpeg_destroy_decompress"));
+        a.ok = a.std_error && a.create && a.mem_src && a.read_header && a.start && a.read_scanlines && a.finish && a.destroy;
+        return a;
+    }();
+    return api;
+}
+
+struct JpegTrap { jmp_buf jb; int code = 0, parm0 = 0; };
+void jpeg_trap_exit(void* cinfo) {          // error_exit: libjpeg must not return from it
+    JpegDecompressHead* c = static_cast<JpegDecompressHead*>(cinfo);
+    JpegTrap* t = static_cast<JpegTrap*>(c->client_data);
+    t->code = c->err->msg_code; t->parm0 = c->err->msg_parm.i[0];
+    longjmp(t->jb, 1);
+}
+void jpeg_quiet(void*) {}
+void jpeg_quiet_emit(void*, int) {}
+
+// width / height / components of the first SOFn marker, parsed independently of the library. False if none is found.
+bool jpeg_sof(const unsigned char* b, size_t n, unsigned& w, unsigned& h, int& comps) {
+    if (n < 4 || b[0] != 0xff || b[1] != 0xd8) return false;
+    size_t i = 2;
+    while (i + 4 <= n) {
+        if (b[i] != 0xff) return false;
+        const unsigned m = b[i + 1];
+        if (m == 0xff) { i++; continue; }                                   // fill byte
+        if (m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { i += 2; continue; }
+        const size_t len = ((size_t)b[i + 2] << 8) | b[i + 3];
+        if (len < 2 || i + 2 + len > n) return false;
+        if (m >= 0xc0 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+            if (len < 8) return false;
+            h = ((unsigned)b[i + 5] << 8) | b[i + 6]; w = ((unsigned)b[i + 7] << 8) | b[i + 8]; comps = b[i + 9];
+            return true;
+        }
+        if (m == 0xda) return false;                                        // scan data before any frame header
+        i += 2 + len;
+    }
+    return false;
+}
+
+// 0 decoded (BGR or grey, 8 bit); 1 not decodable; 2 a flavour / library this build does not take
+int jpeg_load(const std::vector<unsigned char>& file, Pnm& p, std::vector<unsigned char>& pix) {
+    const JpegApi& api = jpeg_api();
+    if (!api.ok) return 2;
+    unsigned sw = 0, shh = 0; int scomp = 0;
+    if (!jpeg_sof(file.data(), file.size(), sw, shh, scomp)) return 1;
+    if (sw == 0 || shh == 0 || sw > 65500 || shh > 65500) return 1;
+    if (scomp != 1 && scomp != 3) return 2;                                 // CMYK / YCCK: left to the caller
+    static int struct_size = 656;                                           // libjpeg-turbo 2.x, v8 ABI, x86-64; corrected by the handshake
+    std::vector<unsigned char> store;
+    JpegErrorMgr err;
+    JpegTrap trap;
+    JpegDecompressHead* volatile c = nullptr;
+    volatile bool created = false;
+    volatile int attempts = 0;
+    std::vector<unsigned char> line;
+    for (;;) {
+        store.assign((size_t)struct_size + 256, 0);
+        c = reinterpret_cast<JpegDecompressHead*>(store.data());
+        std::memset(&err, 0, sizeof err);
+        c->err = api.std_error(&err);
+        err.error_exit = jpeg_trap_exit; err.output_message = jpeg_quiet; err.emit_message = jpeg_quiet_emit;
+        c->client_data = &trap;
+        if (setjmp(trap.jb)) {
+            // JERR_BAD_STRUCT_SIZE is the only error that can arrive before the object exists: msg_parm.i[0] = expected size
+            if (!created && attempts < 2 && trap.parm0 > (int)sizeof(JpegDecompressHead) && trap.parm0 < 4096 && trap.parm0 != struct_size) {
+                struct_size = trap.parm0;
+                continue;
+            }
+            if (created) api.destroy(c);
+            return created ? 1 : 2;
+        }
+        attempts = attempts + 1;
+        api.create(c, 80, (size_t)struct_size);
+        c->client_data = &trap;                                             // jpeg_CreateDecompress zeroes the struct but keeps err
+        created = true;
+        break;
+    }
+    api.mem_src(c, file.data(), (unsigned long)file.size());
+    if (api.read_header(c, 1) != 1) { api.destroy(c); return 1; }
+    // the declared layout must agree with the file: otherwise hands off
+    if (c->image_width != sw || c->image_height != shh || c->num_components != scomp) { api.destroy(c); return 2; }
+    c->out_color_space = scomp == 3 ? 2 : 1;                                // JCS_RGB / JCS_GRAYSCALE (library defaults otherwise)
+    api.start(c);
+    if (c->output_width != sw || c->output_height != shh || c->output_components != scomp || c->output_scanline != 0) { api.destroy(c); return 2; }
+    p.w = (int)sw; p.h = (int)shh; p.cn = scomp; p.depth = 8; p.data_ofs = 0;
+    const size_t row = (size_t)sw * scomp;
+    pix.resize(row * shh);
+    line.resize(row);
+    for (unsigned y = 0; y < shh; y++) {
+        unsigned char* lp = line.data();
+        if (api.read_scanlines(c, &lp, 1) != 1 || c->output_scanline != y + 1) { api.destroy(c); return c->output_scanline != y + 1 ? 2 : 1; }
+        unsigned char* o = pix.data() + row * y;
+        if (scomp == 1) std::memcpy(o, lp, row);
+        else for (unsigned x = 0; x < sw; x++) { o[3 * x] = lp[3 * x + 2]; o[3 * x + 1] = lp[3 * x + 1]; o[3 * x + 2] = lp[3 * x]; }   // RGB -> BGR
+    }
+    api.finish(c);
+    api.destroy(c);
+    return 0;
+}
+
 // 0 ok; else a status with the message set. PNM: `file` holds the file, raster at p.data_ofs; PNG: `file` holds the decoded pixels.
 stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>& file, Pnm& p) {
     if (!path) return fail(ctx, STK_INVALID_PARAMS, "null path");
@@ -215,7 +385,16 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
         return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only stripped 8/16-bit grey or RGB TIFF is decoded in this "
                                               "build (libtiff " + (tiff_api().ok ? "loaded" : "not found") + ")");
     }
-    for (const char* e : {".jpg", ".jpeg", ".jpe", ".bmp", ".webp", ".exr"})
+    if (has_ext(path, ".jpg") || has_ext(path, ".jpeg") || has_ext(path, ".jpe")) {
+        std::vector<unsigned char> raw;
+        if (!read_file(path, raw)) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot read '") + path + "' (empty Mat -> cvtColor fails)");
+        const int rc = jpeg_load(raw, p, file);
+        if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }
+        if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only grey / YCbCr JPEG through libjpeg-turbo's libjpeg.so.8 is decoded "
+                                              "in this build (library " + (jpeg_api().ok ? "loaded" : "not found") + "); decode it on the caller's side");
+    }
+    for (const char* e : {".bmp", ".webp", ".exr"})
         if (has_ext(path, e))
             return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: no codec for '") + path + "' in this build (binary PNM only); decode it "
                                                   "on the caller's side and use the frame-based entry points");

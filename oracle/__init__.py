@@ -32,7 +32,7 @@ def build(force: bool = False) -> str:
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(os.environ.get("STACKER_ORACLE_LIB") or build())     # override: the sanitizer build
         _LIB.orc_ecc_prepare_input.restype = C.c_void_p
     return _LIB
 

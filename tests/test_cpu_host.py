@@ -171,7 +171,8 @@ def test_imread_pnm_without_a_gpu(tmp_path):
     assert np.array_equal(out, img)
     assert lib.stk_imread(None, os.fsencode(p), C.c_void_p(out.ctypes.data), 10, None, None, None, None) == 2      # INVALID_PARAMS
     assert lib.stk_imread(None, os.fsencode(tmp_path / "nope.ppm"), None, 0, None, None, None, None) == 4         # BACKEND_ERROR
-    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.jpg"), None, 0, None, None, None, None) == 7            # NOT_IMPLEMENTED
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.jpg"), None, 0, None, None, None, None) == 4            # missing JPEG: BACKEND_ERROR
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.webp"), None, 0, None, None, None, None) == 7           # no codec: NOT_IMPLEMENTED
 
 
 def test_imread_png_through_runtime_libpng(tmp_path, write_png):
@@ -246,3 +247,68 @@ def test_shard_arithmetic_of_the_library_matches_shard_py():
     f, c = C.c_int32(), C.c_int32()
     assert lib.stk_shard_moving_frames(0, 2, 0, C.byref(f), C.byref(c)) == 2          # STK_INVALID_PARAMS
     assert lib.stk_shard_moving_frames(5, 2, 2, C.byref(f), C.byref(c)) == 2
+
+
+def _conda_pillow_jpegs(tmp_path):
+    """JPEG files written by the Pillow of the image's conda interpreter (the main interpreter has none) and Pillow's own
+    decode of them; None where that interpreter is absent."""
+    import subprocess
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py):
+        return None
+    code = (
+        "import numpy as np, sys\nfrom PIL import Image\nd = sys.argv[1]\nh, w = 123, 211\n"
+        "yy, xx = np.mgrid[0:h, 0:w]\n"
+        "img = np.stack([xx * 255 // w, yy * 255 // h, (xx + yy) * 3 % 256], -1).astype(np.uint8)\n"
+        "img[30:60, 40:90] = [250, 10, 30]\n"
+        "Image.fromarray(img).save(d + '/c444.jpg', quality=92, subsampling=0)\n"
+        "Image.fromarray(img).save(d + '/c420.jpg', quality=85, subsampling=2)\n"
+        "Image.fromarray(img).save(d + '/prog.jpg', quality=85, progressive=True, subsampling=0)\n"
+        "Image.fromarray(img[..., 0]).save(d + '/grey.jpg', quality=90)\n"
+        "np.save(d + '/src.npy', img)\n"
+        "for n in ('c444', 'c420', 'prog', 'grey'):\n    np.save(d + '/' + n + '.npy', np.asarray(Image.open(d + '/' + n + '.jpg')))\n")
+    r = subprocess.run([py, "-c", code, str(tmp_path)], capture_output=True, text=True)
+    if r.returncode != 0:
+        return None
+    return {n: np.load(tmp_path / (n + ".npy")) for n in ("src", "c444", "c420", "prog", "grey")}
+
+
+def test_imread_jpeg_through_runtime_libjpeg(tmp_path):
+    """JPEG (the reference's own data set: README.md:18) through libjpeg-turbo's libjpeg.so.8 loaded at run time, with the
+    struct-size handshake and the SOF cross-check of imread.cpp. Pixels: equal to Pillow's decode where the two decoder
+    families agree by construction (grey; colour without chroma subsampling: <= 1 level), same content otherwise (4:2:0:
+    libjpeg-turbo — OpenCV's decoder — and Pillow's IJG 9 upsample chroma differently)."""
+    lib = _ffi.load()
+    ref = _conda_pillow_jpegs(tmp_path)
+    if ref is None:
+        pytest.skip("no Pillow to write test JPEGs with")
+
+    def read(name, expect=0):
+        w, h, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        st = lib.stk_imread(None, os.fsencode(tmp_path / name), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d))
+        assert st == expect, (name, st)
+        if st:
+            return None
+        out = np.zeros((h.value, w.value, c.value), np.uint8)
+        assert lib.stk_imread(None, os.fsencode(tmp_path / name), C.c_void_p(out.ctypes.data), out.nbytes, None, None, None, None) == 0
+        assert d.value == 8
+        return out
+    g = read("grey.jpg")
+    assert g.shape == (123, 211, 1) and np.array_equal(g[..., 0], ref["grey"])                 # 8UC1, like imread(UNCHANGED)
+    for name in ("c444", "prog"):
+        c = read(name + ".jpg")
+        assert c.shape == (123, 211, 3)
+        assert np.abs(c[..., ::-1].astype(int) - ref[name].astype(int)).max() <= 1               # BGR in memory
+    c420 = read("c420.jpg")
+    assert np.abs(c420[..., ::-1].astype(int) - ref["src"].astype(int)).mean() < 4               # same picture, JPEG noise
+    # a truncated file decodes with the missing part filled in (libjpeg warns and pads; so does OpenCV); garbage does not
+    data = (tmp_path / "c444.jpg").read_bytes()
+    (tmp_path / "trunc.jpg").write_bytes(data[: len(data) // 2])
+    t = read("trunc.jpg")
+    assert t.shape == (123, 211, 3) and np.array_equal(t[:8], read("c444.jpg")[:8])
+    (tmp_path / "garbage.jpg").write_bytes(b"\xff\xd8" + bytes(range(256)) * 4)
+    read("garbage.jpg", expect=4)                                                              # BACKEND_ERROR
+    (tmp_path / "hdr_only.jpg").write_bytes(data[:30])
+    read("hdr_only.jpg", expect=4)
+    (tmp_path / "empty.jpg").write_bytes(b"")
+    read("empty.jpg", expect=4)

@@ -40,8 +40,10 @@ def test_imread_pnm_variants(stacker, tmp_path):
     (tmp_path / "short.ppm").write_bytes(b"P6\n4 4\n255\n\x00\x01")
     with pytest.raises(OpenCvError):
         stacker.imread(tmp_path / "short.ppm")
+    with pytest.raises(OpenCvError):
+        stacker.imread(tmp_path / "photo.jpg")                     # missing file: empty Mat -> cvtColor raises
     with pytest.raises(NotImplementedYet):
-        stacker.imread(tmp_path / "photo.jpg")                     # needs libjpeg: not in this build
+        stacker.imread(tmp_path / "photo.webp")                    # no codec in this build
 
 
 def test_path_based_entry_points_equal_frame_based(stacker, tmp_path):

@@ -1,13 +1,19 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun) from the repo root:  tools/profile_round.sh r01 [bench args...]
-# Produces under gpurun_out/<tag>/: kernel-trace stats, one PMC pass for FETCH_SIZE, one for WRITE_SIZE
-# (separate passes, as MI355X_MICROARCH.md prescribes), and a JSON summary per kernel.
-tag=${1:-r01}; shift
-args="--steps 2 --warmup 1 --no-cpu-baseline $*"
+# Run on the GPU box (through gpurun) from the repo root:  tools/profile_round.sh <tag> [bench args...]
+# Produces under gpurun_out/<tag>/: kernel-trace stats, one PMC pass for FETCH_SIZE, one for WRITE_SIZE (separate
+# passes, as MI355X_MICROARCH.md prescribes: the two do not fit the TCC slots together), one for the SQ issue / stall
+# counters, and a JSON summary per kernel. rocprofv3 gets the program itself after `--` (python3 bench.py ...).
+tag=${1:-r02}; shift
+args="--steps 2 --warmup 1 --no-cpu-baseline --host-fed-steps 0 $*"
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py $args > $out/trace.log 2>&1 || echo "trace pass failed"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_fetch.log 2>&1 || echo "fetch pass failed"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_write.log 2>&1 || echo "write pass failed"
-cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $out > $out/summary.json && cat $out/summary.json | head -60
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py $args > $out/trace.log 2>&1 || echo "trace pass failed"
+echo "trace done"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_fetch.log 2>&1 || echo "fetch pass failed"
+echo "fetch done"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_write.log 2>&1 || echo "write pass failed"
+echo "write done"
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d $out/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_sq.log 2>&1 || echo "sq pass failed"
+echo "sq done"
+cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $out > $out/summary.json && head -c 3000 $out/summary.json
