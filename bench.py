@@ -163,25 +163,28 @@ def main() -> None:
             totals[0], totals[1] = int(counts[0].item()), int(counts[1].item())
             st.finalize_mean(acc, totals[0], out)
 
-    def run_shard(src, acc):
+    def run_shard(src, acc, want_stats=False):
+        # per-frame statistics are marshalled into Python objects only when asked for (the last step): that is host time of
+        # the harness, not of the path
         if api == "ecc":
-            added, stats = st.ecc_match_shard(src, ecc_params, rank == 0, acc)
+            added, stats = st.ecc_match_shard(src, ecc_params, rank == 0, acc, return_stats=want_stats)
             return added, 0, stats
         if api == "hybrid":
-            added, stats = st.hybrid_match_shard(src, kp_params, ecc_params, rank == 0, acc)
+            added, stats = st.hybrid_match_shard(src, kp_params, ecc_params, rank == 0, acc, return_stats=want_stats)
             return added, 0, stats
-        return st.keypoint_match_shard(src, kp_params, rank == 0, acc)
+        return st.keypoint_match_shard(src, kp_params, rank == 0, acc, return_stats=want_stats)
 
-    def step(record: bool):
+    def step(record: bool, last: bool = False):
         nonlocal last_stats, pending, step_no
         acc, counts = accs[step_no % len(accs)], cnts[step_no % len(accs)]
         step_no += 1
-        added, dropped, stats = run_shard(frames, acc)
+        added, dropped, stats = run_shard(frames, acc, want_stats=last)
         if record:
             t = st.timing()
             for k in agg:
                 agg[k] += t[k]
-            last_stats = stats
+            if stats is not None:
+                last_stats = stats
         counts[0] = added
         counts[1] = dropped
         if world == 1:
@@ -215,8 +218,8 @@ def main() -> None:
         step(False)
     fence()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        step(True, last=k == args.steps - 1)
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:

@@ -295,7 +295,7 @@ class Stacker:
 
     # -- shard-level (one process per GPU; frames[0] = reference frame) ------------------------------
     def ecc_match_shard(self, files, params: EccMatchParameters, add_reference: bool, sum_out,
-                        scale_down_width: Optional[float] = None):
+                        scale_down_width: Optional[float] = None, return_stats: bool = True):
         """Un-normalised f32 sum of this rank's aligned frames into `sum_out` (cuda tensor HxWx3)."""
         m = self._marshal(files)
         if m.n == 0:
@@ -307,10 +307,10 @@ class Stacker:
         st = self._lib.stk_ecc_match_shard(self._h, C.byref(m.c_frames), C.byref(p), float(scale_down_width or 0.0),
                                            int(bool(add_reference)), C.byref(img), C.byref(added), stats)
         self._check(st)
-        return added.value, self._stats_list(stats, m.n)
+        return added.value, (self._stats_list(stats, m.n) if return_stats else None)
 
     def keypoint_match_shard(self, files, params: KeyPointMatchParameters, add_reference: bool, sum_out,
-                             scale_down_width: Optional[float] = None):
+                             scale_down_width: Optional[float] = None, return_stats: bool = True):
         m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
@@ -322,7 +322,7 @@ class Stacker:
                                                 float(scale_down_width or 0.0), int(bool(add_reference)),
                                                 C.byref(img), C.byref(added), C.byref(dropped), stats)
         self._check(st)
-        return added.value, dropped.value, self._stats_list(stats, m.n)
+        return added.value, dropped.value, (self._stats_list(stats, m.n) if return_stats else None)
 
     def finalize_mean(self, sum_img, n_frames: int, out=None):
         """img / n  (lib.rs:339-345, 836-839) on a cuda tensor; in place when out is None."""
@@ -372,7 +372,7 @@ class Stacker:
         return (out, self._stats_list(stats, m.n)) if return_stats else out
 
     def hybrid_match_shard(self, files, kp_params: KeyPointMatchParameters, ecc_params: EccMatchParameters,
-                           add_reference: bool, sum_out):
+                           add_reference: bool, sum_out, return_stats: bool = True):
         m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")
@@ -382,7 +382,7 @@ class Stacker:
         kp, ep = kp_params._c(), ecc_params._c()
         self._check(self._lib.stk_hybrid_match_shard(self._h, C.byref(m.c_frames), C.byref(kp), C.byref(ep),
                                                      int(bool(add_reference)), C.byref(img), C.byref(added), stats))
-        return added.value, self._stats_list(stats, m.n)
+        return added.value, (self._stats_list(stats, m.n) if return_stats else None)
 
     # -- file front-end: the reference's entry points take paths ------------------------------
     def imread(self, path):

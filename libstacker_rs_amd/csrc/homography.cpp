@@ -163,11 +163,16 @@ int find_homography_batch(stk_ctx* ctx, hipStream_t stream, HgWorkspace* ws, con
     HIP_TRY(ws->jobs.reserve(sizeof(HgJob) * L));
     HIP_TRY(ws->results.reserve(sizeof(HgResult) * L));
     HIP_TRY(ws->frames.reserve(sizeof(HgFrame) * L));
-    const size_t stage_fixed = n_points * sizeof(HgPoint) + n_points + (sizeof(HgJob) + sizeof(HgResult) + sizeof(HgFrame)) * (size_t)L;
-    HIP_TRY(ensure_pinned(ws, stage_fixed + 64));
+    // pinned staging, laid out once for the whole call so that no region is reused while a copy may still read it:
+    // [points][jobs][results][masks][per-round: samples, scores, frames — worst case 2000 samples per problem]
+    const size_t stage_fixed = n_points * sizeof(HgPoint) + n_points + (sizeof(HgJob) + sizeof(HgResult)) * (size_t)L + 64;
+    const size_t round_max = ((sizeof(HgSample) + sizeof(int)) * (size_t)2000 + sizeof(HgFrame)) * (size_t)L + 64;
+    HIP_TRY(ensure_pinned(ws, stage_fixed + round_max));
+    uint8_t* const pin = (uint8_t*)ws->pinned;
+    uint8_t* const round_area = pin + ((stage_fixed + 63) & ~(size_t)63);
     std::vector<Track> tracks(L);
     {
-        HgPoint* hp = (HgPoint*)ws->pinned;
+        HgPoint* hp = (HgPoint*)pin;
         size_t ofs = 0;
         for (int k = 0; k < L; k++) {
             const HgProblem& pr = probs[live[k]];
@@ -177,7 +182,6 @@ int find_homography_batch(stk_ctx* ctx, hipStream_t stream, HgWorkspace* ws, con
             ofs += (size_t)pr.n;
         }
         HIP_TRY(hipMemcpyAsync(ws->pts.p, hp, n_points * sizeof(HgPoint), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));        // the staging area is reused below
     }
 
     // ---- robust stage: rounds of speculative model evaluation -------------------------------------------------------
@@ -219,9 +223,7 @@ int find_homography_batch(stk_ctx* ctx, hipStream_t stream, HgWorkspace* ws, con
         HIP_TRY(ws->samples.reserve(sizeof(HgSample) * (size_t)hyp_total));
         HIP_TRY(ws->scores.reserve(sizeof(int) * (size_t)hyp_total));
         if (lmeds) HIP_TRY(ws->err.reserve(sizeof(float) * err_total));
-        const size_t stage = (sizeof(HgSample) + sizeof(int)) * (size_t)hyp_total + sizeof(HgFrame) * (size_t)n_active;
-        HIP_TRY(ensure_pinned(ws, std::max(stage, stage_fixed) + 64));
-        HgSample* hs = (HgSample*)ws->pinned;
+        HgSample* hs = (HgSample*)round_area;                     // the previous round ended with a stream synchronisation
         int* hscore = (int*)(hs + hyp_total);
         HgFrame* hf = (HgFrame*)(hscore + hyp_total);
         int fi = 0;
@@ -272,8 +274,7 @@ int find_homography_batch(stk_ctx* ctx, hipStream_t stream, HgWorkspace* ws, con
             j.thr2 = (float)(sigma * sigma);
         } else j.thr2 = thr2;
     }
-    HIP_TRY(ensure_pinned(ws, stage_fixed + 64));
-    HgJob* hj = (HgJob*)ws->pinned;
+    HgJob* hj = (HgJob*)(pin + n_points * sizeof(HgPoint));
     HgResult* hr = (HgResult*)(hj + L);
     uint8_t* hm = (uint8_t*)(hr + L);
     std::memcpy(hj, jobs.data(), sizeof(HgJob) * L);

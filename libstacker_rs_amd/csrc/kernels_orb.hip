@@ -387,16 +387,32 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict
     }
 }
 
-__global__ void fast_threshold_kernel(OrbLevelState* st, int keep, OrbBatch bs) {
-    if (threadIdx.x != 0) return;
+// retainBest(2 n_l) by FAST score: the largest score s whose "count of candidates >= s" reaches `keep`. One wavefront per
+// (frame, level): lane L owns bins 4 L .. 4 L + 3, an inclusive suffix sum over the lanes gives every bin its count from
+// the top, and the answer is the largest bin whose suffix count reaches `keep` (1 if none does) — what the serial scan
+// from 255 downwards returns.
+__global__ __launch_bounds__(64) void fast_threshold_kernel(OrbLevelState* st, int keep, OrbBatch bs) {
     st += blockIdx.x * bs.states;
-    int cum = 0, thr = 1;
-    for (int s = 255; s >= 1; s--) {
-        cum += st->hist[s];
-        if (cum >= keep) { thr = s; break; }
+    const int lane = threadIdx.x;
+    const int4 h4 = *reinterpret_cast<const int4*>(st->hist + 4 * lane);
+    const int mine = h4.x + h4.y + h4.z + h4.w;
+    int suffix = mine;                                   // sum over lanes >= this one
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_down(suffix, o, 64);
+        if (lane + o < 64) suffix += v;
     }
-    st->threshold = keep > 0 ? thr : 256;
-    st->n_sel = 0;
+    const int above = suffix - mine;                     // candidates in bins of higher lanes
+    int best = 0;                                        // largest qualifying bin of this lane (0: none)
+    int cum = above + h4.w;
+    if (cum >= keep) best = 4 * lane + 3;
+    else { cum += h4.z; if (cum >= keep) best = 4 * lane + 2; else { cum += h4.y; if (cum >= keep) best = 4 * lane + 1; else { cum += h4.x; if (cum >= keep) best = 4 * lane; } } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o, 64));
+    if (lane == 0) {
+        st->threshold = keep > 0 ? max(best, 1) : 256;    // bin 0 is never a candidate score
+        st->n_sel = 0;
+    }
 }
 
 // Short list: candidates >= threshold, then the Harris response (blockSize 7, Sobel-like 3x3 on the 8-bit level,

@@ -184,7 +184,13 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     // the head of every short list in one strided copy (rows = (frame, level), ORB_PACK of ORB_SEL_CAP entries each)
     HIP_TRY(hipMemcpy2DAsync(ws->host_sel, sizeof(OrbSelected) * ORB_PACK, ws->sel.p, sizeof(OrbSelected) * ORB_SEL_CAP,
                              sizeof(OrbSelected) * ORB_PACK, (size_t)ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventRecord(ctx->gate_ev, s));
+    // The 7x7 blur of every level (the descriptor stage's input) does not depend on the host's Harris cull: it is queued
+    // now and runs while the host works on the short lists (the host waits for the copies above only, not for the stream).
+    for (int l = 0; l < ORB_LEVELS; l++)
+        HIP_TRY(launch_gauss7(pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], g.g7, ws->tmpf.as<float>(), ws->blur.as<uint8_t>() + g.pyr.ofs[l], s,
+                              n_frames, PT, tmp_stride));
+    HIP_TRY(hipEventSynchronize(ctx->gate_ev));
     if (timed) ctx->timing.fast_ms += ev_ms(ctx->ev[6], ctx->ev[7]);
     // rare: a level with more short-listed corners than ORB_PACK (many tied FAST scores) is fetched whole
     std::vector<std::vector<OrbSelected>> big((size_t)n_frames * ORB_LEVELS);
@@ -242,12 +248,9 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     });
     std::vector<OrbFinalKeypoint> all;
     for (auto& fin : fins) all.insert(all.end(), fin.begin(), fin.end());
-    if (all.empty()) return STK_OK;
+    if (all.empty()) { HIP_TRY(hipStreamSynchronize(s)); return STK_OK; }
     HIP_TRY(ws->final_kps.reserve(sizeof(OrbFinalKeypoint) * all.size()));
     HIP_TRY(hipMemcpyAsync(ws->final_kps.p, all.data(), sizeof(OrbFinalKeypoint) * all.size(), hipMemcpyHostToDevice, s));
-    for (int l = 0; l < ORB_LEVELS; l++)
-        HIP_TRY(launch_gauss7(pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], g.g7, ws->tmpf.as<float>(), ws->blur.as<uint8_t>() + g.pyr.ofs[l], s,
-                              n_frames, PT, tmp_stride));
     HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)all.size(), desc_dev, s, PT));
     HIP_TRY(hipStreamSynchronize(s));     // `all` is read by the async copy above
     return STK_OK;
