@@ -285,6 +285,17 @@ constexpr int FT_TW = FT_X + 2 * FT_H;               // 136 bytes per image-tile
 constexpr int FT_TH = FT_Y + 2 * FT_H;               // 40 rows
 constexpr int FT_SW = FT_X + 4, FT_SH = FT_Y + 2;    // score region 130 x 34, stored with a row stride of 132
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {       // v_pk_sub_i16
+    return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {       // v_pk_add_i16
+    return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ int mbcnt64(unsigned long long mask) {              // set bits of `mask` below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
 __device__ __forceinline__ bool has_arc9(uint32_t m) {          // 16-bit circular mask: 9 contiguous ones?
     const uint32_t mm = m | (m << 16);                           // unrolled circle: bit k + 16 == bit k
     const uint32_t a = mm & (mm >> 1), b = a & (a >> 2), c = b & (b >> 4);
@@ -318,17 +329,62 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
     __syncthreads();
     // score-region pixel id = sy * FT_SW + sx, sx in [0, 130), sy in [0, 34); image pixel (x0 - 1 + sx, y0 - 1 + sy);
     // its byte in T is at row sy + 3, column sx + 3
-    // pass 1: compass pre-test
-    for (int i = tid; i < FT_SH * (FT_X + 2); i += 256) {
-        const int sy = i / (FT_X + 2), sx = i - sy * (FT_X + 2);
-        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
-        if (x < 3 || x >= w - 3 || y < 3 || y >= h - 3) continue;
-        const uint8_t* p = T + (sy + 3) * FT_TW + sx + 3;
-        const int v = p[0];
-        const int n0 = v - p[3 * FT_TW], n4 = v - p[3], n8 = v - p[-3 * FT_TW], n12 = v - p[-3];
-        const int dark = (n0 > thr) + (n4 > thr) + (n8 > thr) + (n12 > thr);
-        const int bright = (n0 < -thr) + (n4 < -thr) + (n8 < -thr) + (n12 < -thr);
-        if (dark >= 2 || bright >= 2) listA[atomicAdd(&nA, 1)] = (unsigned short)(sy * FT_SW + sx);
+    // pass 1: compass pre-test, FOUR pixels per lane. A lane takes one aligned dword of a tile row (4 centre pixels), the
+    // dwords 3 rows above / below it and its two row neighbours (east / west taps by v_alignbyte), unpacks bytes to 16-bit
+    // pairs (v_perm) and does the eight threshold tests per pixel with packed 16-bit subtractions whose SIGN bits are the
+    // comparison results: centre - tap > thr  <=>  thr - (centre - tap) < 0, centre - tap < -thr  <=>  (centre - tap) + thr < 0.
+    // "At least two of the four compass taps" is then pure bit logic on the sign bits. Pixels that pass are appended to
+    // list A with one LDS atomic per wavefront and step (ballot + mbcnt), not one per pixel.
+    {
+        constexpr int ROW_DW = FT_TW / 4;                               // 34 dwords per tile row
+        const uint32_t T2 = (uint32_t)thr | ((uint32_t)thr << 16);
+        const int lane = tid & 63;
+        for (int i0 = tid - lane; i0 < FT_SH * ROW_DW; i0 += 256) {      // wave-uniform trip count
+            const int i = i0 + lane;
+            const bool act = i < FT_SH * ROW_DW;
+            const int sy = act ? i / ROW_DW : 0, dq = act ? i - sy * ROW_DW : 0;
+            const uint32_t* R = reinterpret_cast<const uint32_t*>(T + (sy + 3) * FT_TW);
+            const uint32_t c0 = R[dq];
+            const uint32_t cm = R[max(dq - 1, 0)], cp = R[min(dq + 1, ROW_DW - 1)];     // clamped reads feed invalid pixels only
+            const uint32_t nn = reinterpret_cast<const uint32_t*>(T + sy * FT_TW)[dq];
+            const uint32_t ss = reinterpret_cast<const uint32_t*>(T + (sy + 6) * FT_TW)[dq];
+            const uint32_t ee = __builtin_amdgcn_alignbyte(cp, c0, 3);   // columns +3: bytes c0[3] cp[0] cp[1] cp[2]
+            const uint32_t ww = __builtin_amdgcn_alignbyte(c0, cm, 1);   // columns -3: bytes cm[1] cm[2] cm[3] c0[0]
+            uint32_t r[2];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const uint32_t sel = half ? 0x0c030c02u : 0x0c010c00u;   // bytes (2, 3) or (0, 1) into the low bytes of two 16-bit lanes
+                const uint32_t C = __builtin_amdgcn_perm(0u, c0, sel);
+                uint32_t dk[4], br[4];
+                const uint32_t taps[4] = {nn, ee, ss, ww};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t D = pk_sub_i16(C, __builtin_amdgcn_perm(0u, taps[d], sel));
+                    dk[d] = pk_sub_i16(T2, D);                           // sign set: centre darker-side test (D > thr)
+                    br[d] = pk_add_i16(D, T2);                           // sign set: D < -thr
+                }
+                r[half] = (((dk[0] | dk[1]) & (dk[2] | dk[3])) | (dk[0] & dk[1]) | (dk[2] & dk[3])) |
+                          (((br[0] | br[1]) & (br[2] | br[3])) | (br[0] & br[1]) | (br[2] & br[3]));
+            }
+            uint32_t m = ((r[0] >> 15) & 1u) | ((r[0] >> 30) & 2u) | ((r[1] >> 13) & 4u) | ((r[1] >> 28) & 8u);
+            // pixel k of this dword: sx = 4 dq - 3 + k in [0, FT_X + 2), image x = x0 - 4 + 4 dq + k in [3, w - 3), y likewise
+            const int xq = x0 - 4 + 4 * dq, y = y0 - 1 + sy;
+            const int klo = max(max(3 - 4 * dq, 3 - xq), 0), khi = min(min(FT_X + 5 - 4 * dq, w - 3 - xq), 4);
+            const uint32_t vm = (act && y >= 3 && y < h - 3 && khi > klo) ? ((1u << khi) - 1u) & ~((1u << klo) - 1u) : 0u;
+            m &= vm;
+            const unsigned long long b0 = __ballot(m & 1u), b1 = __ballot(m & 2u), b2 = __ballot(m & 4u), b3 = __ballot(m & 8u);
+            const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+            if (n0 + n1 + n2 + n3) {                                      // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&nA, n0 + n1 + n2 + n3);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int id = sy * FT_SW + 4 * dq - 3;
+                if (m & 1u) listA[base + mbcnt64(b0)] = (unsigned short)id;
+                if (m & 2u) listA[base + n0 + mbcnt64(b1)] = (unsigned short)(id + 1);
+                if (m & 4u) listA[base + n0 + n1 + mbcnt64(b2)] = (unsigned short)(id + 2);
+                if (m & 8u) listA[base + n0 + n1 + n2 + mbcnt64(b3)] = (unsigned short)(id + 3);
+            }
+        }
     }
     __syncthreads();
     // pass 2: ring masks, 9 contiguous
