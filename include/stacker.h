@@ -173,6 +173,8 @@ void        stk_host_free(void* p);
  *                        (changes results: it selects the other OpenCV behaviour)
  *   "profile"            0 off, 1 per-stage events (stk_get_timing), 2 + event pairs around ECC launches
  *   "profile_stride"     with profile = 2: bracket every n-th ECC launch only
+ *   "prep_stream"        1 (default): ECC templates of a run of frames by the streaming grey + blur kernel, one launch per
+ *                        run; 0: the LDS-tiled kernel, frame by frame. Same bits either way
  *   "upload_batch"       host-fed stacks: frames per host -> HBM batch (default 8); a batch is the unit the ECC queue
  *                        and the batched ORB wait for */
 stk_status  stk_set_option(stk_ctx* ctx, const char* name, int64_t value);

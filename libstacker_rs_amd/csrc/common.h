@@ -122,6 +122,10 @@ hipError_t launch_bgr16_to_grey8(const void* bgr16, int w, int h, size_t stride_
                                  size_t src_frame_bytes = 0, size_t out_frame_elems = 0);
 hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, size_t stride_bytes, int ksize,
                             float* out, int out_stride, hipStream_t s);
+// the same for n BGR frames (u8 / u16) in one launch (frame z: ptrs_dev[z], or base + z * frame_bytes when ptrs_dev is null),
+// plane z written at out + z * out_plane_stride; hipErrorNotSupported if the streaming kernel does not apply
+hipError_t launch_grey_blur_batch(const void* const* ptrs_dev, const void* base, size_t frame_bytes, int n, int depth, int w, int h,
+                                  size_t stride_bytes, int ksize, float* out, int out_stride, size_t out_plane_stride, hipStream_t s);
 // blurred plane (stride in_stride) -> padded I/gx/gy planes
 hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
                              int ref_stride, hipStream_t s);

@@ -40,6 +40,7 @@ struct stk_ctx {
     std::vector<hipEvent_t> upload_events;
     hipEvent_t gate_ev = nullptr;
     int opt_warp_tune = 0;
+    int opt_prep_stream = 1;              // 1: templates of a run of frames by the streaming grey+blur kernel in one launch; 0: tiled kernel, frame by frame
     int opt_upload_batch = 8;             // frames per host -> HBM batch
     std::string err;
     int opt_ecc_slots = 0;        // 0 = auto

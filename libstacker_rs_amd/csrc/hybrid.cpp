@@ -23,6 +23,7 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
     if (ecc_params->motion_type != STK_MOTION_HOMOGRAPHY)
         return fail(ctx, STK_INVALID_PARAMS, "hybrid match seeds a homography: motion type must be Homography");
     const int n = frames->n;
+    timing_begin(ctx);
     std::vector<KpAlign> al;
     std::vector<const void*> dev;
     int n0 = 0;
@@ -44,8 +45,11 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
     devf.data = devp.data();
     devf.location = STK_DEVICE;
     const double alpha = frames->depth == 16 ? 1.0 / 65535.0 : 1.0 / 255.0;
+    const stk_timing kp_t = ctx->timing;                      // upload + ORB figures of the alignment step above
     st = ecc_shard_impl(ctx, &devf, ecc_params, 0.f, add_reference, sum, n_added, stats, seeds.data(), alpha, true);
     if (st) return st;
+    ctx->timing.h2d_ms = kp_t.h2d_ms; ctx->timing.h2d_bytes = kp_t.h2d_bytes;
+    ctx->timing.fast_ms = kp_t.fast_ms; ctx->timing.fast_launches = kp_t.fast_launches; ctx->timing.fast_pixels = kp_t.fast_pixels;
     if (stats)
         for (int i = 0; i < n; i++) { stats[i].n_keypoints = i ? al[i].n_keypoints : n0; stats[i].n_matches = al[i].n_matches; stats[i].n_inliers = al[i].n_inliers; }
     return STK_OK;

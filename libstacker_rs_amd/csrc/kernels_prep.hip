@@ -292,6 +292,135 @@ __global__ __launch_bounds__(256) void grey_blur_u8c3_kernel(const T* __restrict
     }
 }
 
+// ---- fused grey + Gaussian blur, streaming form: a whole batch of frames in one launch -------------------------------
+// The tiled kernel above is bound by its two workgroup barriers and by the occupancy its 38 KB of LDS allows (rocprofv3:
+// waves parked 70 % of their cycles, 2.5 TB/s). This one uses no LDS and no barrier: a lane owns a 4-pixel-wide column
+// strip and walks down GS_SEG + 2 R rows; per row it loads its own 12 bytes (4 BGR pixels, one aligned dwordx3), makes
+// the four grey values, fetches the R neighbours on each side from the adjacent lanes (cross-lane moves; the first and
+// last lane of a wave only feed their neighbours, so waves overlap by two quads), row-filters, keeps the last 2 R + 1
+// row results in registers and column-filters one output row per step (one float4 store). Rows are prefetched GS_PF
+// deep. Same arithmetic in the same order as the tiled kernel: bit-identical planes. Enough waves to fill the chip come
+// from batching the frames of a shard (blockIdx.z); single frames keep the tiled kernel.
+constexpr int GS_SEG = 32, GS_PF = 4, GS_QW = 62;         // output rows per segment, rows in flight, output quads per wave
+
+template <typename T> struct QuadRaw;
+template <> struct QuadRaw<uint8_t> { uint32_t d[3]; };
+template <> struct QuadRaw<uint16_t> { uint32_t d[6]; };
+
+__device__ __forceinline__ float4 quad_grey(const QuadRaw<uint8_t>& r) {      // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+    const uint32_t d0 = r.d[0], d1 = r.d[1], d2 = r.d[2];
+    return make_float4((float)grey_u8(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u), (float)grey_u8(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u),
+                       (float)grey_u8((d1 >> 16) & 255u, d1 >> 24, d2 & 255u), (float)grey_u8((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24));
+}
+__device__ __forceinline__ float4 quad_grey(const QuadRaw<uint16_t>& r) {     // b0 g0 | r0 b1 | g1 r1 | b2 g2 | r2 b3 | g3 r3
+    const uint32_t* d = r.d;
+    return make_float4((float)grey_u16(d[0] & 0xffffu, d[0] >> 16, d[1] & 0xffffu), (float)grey_u16(d[1] >> 16, d[2] & 0xffffu, d[2] >> 16),
+                       (float)grey_u16(d[3] & 0xffffu, d[3] >> 16, d[4] & 0xffffu), (float)grey_u16(d[4] >> 16, d[5] & 0xffffu, d[5] >> 16));
+}
+
+struct FrameBatch { const void* const* ptrs; const void* base; size_t frame_bytes; };   // frame z: ptrs[z], or base + z * frame_bytes
+
+template <int R, typename T>
+__global__ __launch_bounds__(256) void grey_blur_stream_kernel(FrameBatch fb, size_t stride /* elements of T per row */, int w, int h,
+                                                               GaussTaps taps, float* __restrict__ out, int out_stride, size_t out_plane_stride) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = w >> 2;
+    if (wv * GS_QW >= nq) return;                                  // wave-uniform: this wave lies beyond the frame
+    const int q = wv * GS_QW + lane - 1;                           // quad owned by this lane
+    const int qc = min(max(q, 0), nq - 1);
+    const bool writer = (lane >= 1) & (lane <= GS_QW) & (q < nq);
+    const int y0 = blockIdx.y * GS_SEG;
+    const T* __restrict__ src = fb.ptrs ? (const T*)fb.ptrs[blockIdx.z] : (const T*)((const char*)fb.base + blockIdx.z * fb.frame_bytes);
+    float* __restrict__ dst = out + blockIdx.z * out_plane_stride + 4 * (size_t)qc;
+    float k[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; j++) k[j] = taps.k[j];
+    constexpr int NT = GS_SEG + 2 * R;
+    auto load_row = [&](int t) {
+        const int sy = reflect101(y0 - R + min(t, NT - 1), h);
+        QuadRaw<T> r;
+        __builtin_memcpy(&r, src + (size_t)sy * stride + (size_t)qc * 12, sizeof(r));     // 4 pixels x 3 channels
+        return r;
+    };
+    QuadRaw<T> pf[GS_PF];
+#pragma unroll
+    for (int i = 0; i < GS_PF; i++) pf[i] = load_row(i);
+    float4 ring[2 * R + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * R + 1; i++) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < NT; t++) {
+        const QuadRaw<T> cur = pf[0];
+#pragma unroll
+        for (int i = 0; i + 1 < GS_PF; i++) pf[i] = pf[i + 1];
+        pf[GS_PF - 1] = load_row(t + GS_PF);
+        const float4 g = quad_grey(cur);
+        float f[4 + 2 * R];
+        f[R] = g.x; f[R + 1] = g.y; f[R + 2] = g.z; f[R + 3] = g.w;
+        // neighbours: position -j is component 4 - j of the lane to the left, position 3 + j component j - 1 of the lane to the right
+        const float lw = __shfl_up(g.w, 1, 64), lz = __shfl_up(g.z, 1, 64), rx = __shfl_down(g.x, 1, 64), ry = __shfl_down(g.y, 1, 64);
+        f[R - 1] = lw; f[R + 4] = rx;
+        if (R >= 2) { f[R - 2] = lz; f[R + 5] = ry; }
+        if (R >= 3) { f[R - 3] = __shfl_up(g.y, 1, 64); f[R + 6] = __shfl_down(g.z, 1, 64); }
+        if (q == 0) {                                              // REFLECT_101 at the left edge: -1 -> 1, -2 -> 2, -3 -> 3
+            f[R - 1] = g.y;
+            if (R >= 2) f[R - 2] = g.z;
+            if (R >= 3) f[R - 3] = g.w;
+        }
+        if (q == nq - 1) {                                         // right edge: w -> w - 2, w + 1 -> w - 3, w + 2 -> w - 4
+            f[R + 4] = g.z;
+            if (R >= 2) f[R + 5] = g.y;
+            if (R >= 3) f[R + 6] = g.x;
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float sacc = k[0] * f[R + e];
+#pragma unroll
+            for (int j = 1; j <= R; j++) sacc += k[j] * (f[R + e - j] + f[R + e + j]);
+            o[e] = sacc;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * R; i++) ring[i] = ring[i + 1];
+        ring[2 * R] = make_float4(o[0], o[1], o[2], o[3]);
+        const int y = y0 + t - 2 * R;
+        if (t >= 2 * R && y < h && writer) {
+            float4 sacc;
+            sacc.x = k[0] * ring[R].x; sacc.y = k[0] * ring[R].y; sacc.z = k[0] * ring[R].z; sacc.w = k[0] * ring[R].w;
+#pragma unroll
+            for (int j = 1; j <= R; j++) {
+                sacc.x += k[j] * (ring[R - j].x + ring[R + j].x);
+                sacc.y += k[j] * (ring[R - j].y + ring[R + j].y);
+                sacc.z += k[j] * (ring[R - j].z + ring[R + j].z);
+                sacc.w += k[j] * (ring[R - j].w + ring[R + j].w);
+            }
+            *reinterpret_cast<float4*>(dst + (size_t)y * out_stride) = sacc;
+        }
+    }
+}
+
+// GaussianBlur(float(grey(frame))) of n frames in one launch; hipErrorNotSupported when the streaming kernel does not
+// apply (the caller then takes launch_grey_blur frame by frame): 8- or 16-bit BGR, kernel size 3 / 5 / 7, width a multiple
+// of 4 and >= 8, dword-aligned rows and frames, 16-byte-aligned output rows.
+hipError_t launch_grey_blur_batch(const void* const* ptrs_dev, const void* base, size_t frame_bytes, int n, int depth, int w, int h,
+                                  size_t stride_bytes, int ksize, float* out, int out_stride, size_t out_plane_stride, hipStream_t s) {
+    GaussTaps taps;
+    if (!gaussian_taps(ksize, taps)) return hipErrorInvalidValue;
+    const int r = taps.r;
+    if (n <= 0) return hipSuccess;
+    if ((depth != 8 && depth != 16) || r < 1 || r > 3 || w % 4 != 0 || w < 8 || stride_bytes % 4 != 0 || out_stride % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(out) & 15) != 0 || out_plane_stride % 4 != 0 ||
+        (!ptrs_dev && ((reinterpret_cast<uintptr_t>(base) & 3) != 0 || frame_bytes % 4 != 0)))
+        return hipErrorNotSupported;
+    const int waves = (w / 4 + GS_QW - 1) / GS_QW;
+    dim3 grid((waves + 3) / 4, (h + GS_SEG - 1) / GS_SEG, n);
+    const FrameBatch fb{ptrs_dev, base, frame_bytes};
+#define STK_GBS(R, T) grey_blur_stream_kernel<R, T><<<grid, 256, 0, s>>>(fb, stride_bytes / sizeof(T), w, h, taps, out, out_stride, out_plane_stride)
+    if (depth == 8) { if (r == 1) STK_GBS(1, uint8_t); else if (r == 2) STK_GBS(2, uint8_t); else STK_GBS(3, uint8_t); }
+    else { if (r == 1) STK_GBS(1, uint16_t); else if (r == 2) STK_GBS(2, uint16_t); else STK_GBS(3, uint16_t); }
+#undef STK_GBS
+    return hipGetLastError();
+}
+
 hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, size_t stride_bytes, int ksize,
                             float* out, int out_stride, hipStream_t s) {
     GaussTaps taps;

@@ -157,6 +157,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
     else if (n == "warp_tune") ctx->opt_warp_tune = (int)value;
+    else if (n == "prep_stream") ctx->opt_prep_stream = value != 0;
     else if (n == "upload_batch") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "upload_batch out of range"); ctx->opt_upload_batch = (int)value; }
     else if (n == "ecc_blocks") { if (value != 0 && (value < 8 || value > 65536)) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
@@ -459,6 +460,23 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         HIP_TRY(launch_grey_blur(gsmall, 8, 1, ew, eh, (size_t)ew, params->gauss_filt_size, t, pl.templ_row_stride, s));
         return STK_OK;
     };
+    // templates of frames [first, first + count): one streaming launch for the whole run when the frames are evenly spaced
+    // in memory (a tensor, or the engine's own upload buffer) and the kernel applies, else frame by frame
+    auto prepare_templates = [&](int first, int count, hipStream_t s) -> stk_status {
+        if (count <= 0) return STK_OK;
+        bool even = !scaled && count >= 2 && ctx->opt_prep_stream;
+        const ptrdiff_t step = count >= 2 ? (const char*)dev[first + 1] - (const char*)dev[first] : 0;
+        for (int k = 1; even && k + 1 < count; k++) even = ((const char*)dev[first + k + 1] - (const char*)dev[first + k]) == step;
+        if (even && step > 0) {
+            const hipError_t e = launch_grey_blur_batch(nullptr, dev[first], (size_t)step, count, frames->depth, w, h, rb, params->gauss_filt_size,
+                                                        ctx->templates.as<float>() + pl.templ_plane_stride * (size_t)(first - 1), pl.templ_row_stride,
+                                                        pl.templ_plane_stride, s);
+            if (e == hipSuccess) return STK_OK;
+            if (e != hipErrorNotSupported) return fail(ctx, STK_HIP_ERROR, std::string("grey_blur batch: ") + hipGetErrorString(e));
+        }
+        for (int k = 0; k < count; k++) { const stk_status ps = prepare_template(first + k, s); if (ps) return ps; }
+        return STK_OK;
+    };
     auto prepare_reference = [&](hipStream_t s) -> stk_status {
         if (!scaled) return ecc_prepare_reference(ctx, pl, dev[0], frames->depth, 3, rb, params->gauss_filt_size);
         HIP_TRY(launch_grey(dev[0], 8, w, h, rb, gfull, s));
@@ -469,8 +487,7 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     if (host_fed && (st = up.wait_batch(0, ctx->stream))) return bail(st);
     if ((st = prepare_reference(ctx->stream))) return bail(st);
-    if (!host_fed)
-        for (int i = 1; i < n; i++) if ((st = prepare_template(i, ctx->stream))) return st;
+    if (!host_fed && (st = prepare_templates(1, n - 1, ctx->stream))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     const float* seeds_dev = nullptr;
     if (seeds && n > 1) {
@@ -489,8 +506,7 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
             while (next_batch < up.batches() && (block || up.recorded() > next_batch)) {
                 stk_status fs = up.wait_batch(next_batch, ps);
                 if (fs) return fs;
-                for (int k = 0; k < up.batch_count(next_batch); k++)
-                    if ((fs = prepare_template(up.batch_first(next_batch) + k, ps))) return fs;
+                if ((fs = prepare_templates(up.batch_first(next_batch), up.batch_count(next_batch), ps))) return fs;
                 enq = up.batch_first(next_batch) + up.batch_count(next_batch) - 1;        // templates 0 .. enq-1 exist
                 HIP_TRY(launch_ecc_set_ready(q, enq, ps));
                 next_batch++;

@@ -221,3 +221,35 @@ def test_ecc_match_f32_frames(stacker, small_stack):
     # 16-bit frames: the reference's grey is 16UC1, which findTransformECC rejects -> OpenCvError
     with pytest.raises(OpenCvError):
         stacker.ecc_match([f.astype(np.uint16) for f in frames[:2]], PARAMS)
+
+
+@pytest.mark.parametrize("depth,gauss", [(8, 3), (8, 5), (8, 7), (16, 5)])
+def test_streaming_grey_blur_is_bit_identical_to_the_tiled_kernel(stacker, depth, gauss):
+    # the templates of a run of frames come from grey_blur_stream_kernel (no LDS, cross-lane halo, one launch per run); the
+    # tiled kernel — itself bit-exact against the oracle (test_gpu_stages / test_gpu_fullsize) — must give the same planes,
+    # hence the same ECC trajectory and the same stacked bits. Widths: several waves across, a ragged last wave, one quad row
+    import torch
+    from libstacker_rs_amd import KeyPointMatchParameters, RANSAC
+    for w, h in ((1000, 70), (256, 33), (8, 40)):
+        frames, _ = synth.make_stack(5, max(w, 64), max(h, 64), depth=depth)
+        fr = frames[:, :h, :w].contiguous().cuda()
+        p = EccMatchParameters(MotionType.Homography, 4, None, gauss)
+        run = (lambda: stacker.ecc_match(fr, p, return_stats=True)) if depth == 8 else \
+              (lambda: stacker.hybrid_match(fr, KeyPointMatchParameters(RANSAC, 5.0, 0.8, 0.9), p, return_stats=True))
+        try:
+            a, sa = run()
+        except Exception as e:                      # a sliver this small may not correlate: both paths must then fail alike
+            a, sa = None, repr(type(e))
+        stacker.set_option("prep_stream", 0)
+        try:
+            try:
+                b, sb = run()
+            except Exception as e:
+                b, sb = None, repr(type(e))
+        finally:
+            stacker.set_option("prep_stream", 1)
+        if a is None or b is None:
+            assert a is None and b is None and sa == sb
+            continue
+        assert torch.equal(a, b)
+        assert all(np.array_equal(x["warp"], y["warp"]) and x["rho"] == y["rho"] for x, y in zip(sa, sb))

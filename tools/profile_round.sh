@@ -16,4 +16,7 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 echo "write done"
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d $out/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_sq.log 2>&1 || echo "sq pass failed"
 echo "sq done"
-cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $out > $out/summary.json && head -c 3000 $out/summary.json
+cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $out > $out/summary.json && head -c 1500 $out/summary.json
+# keep what is judged (per-kernel stats + summary), drop the raw per-dispatch traces (tens of MB; gpurun_out is capped)
+cp $out/trace/*/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
+rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_sq
