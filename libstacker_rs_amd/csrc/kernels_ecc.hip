@@ -289,6 +289,9 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 // one pixel in flight between the two pipeline stages of the row-factorised pass
+#ifndef STK_H8_WG
+#define STK_H8_WG 4
+#endif
 struct H8Px {
     float sx, sy, rw, ax, ay, tval;
     f32x2_a4 i0, i1;
@@ -296,7 +299,7 @@ struct H8Px {
     int x;
 };
 
-__global__ __launch_bounds__(256, 3) void ecc_iter_h8_kernel(EccIterArgs a) {   // 3 workgroups per CU: <= 168 VGPRs
+__global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8_kernel(EccIterArgs a) {   // STK_H8_WG workgroups per CU
     constexpr int MOTION = STK_MOTION_HOMOGRAPHY;
     constexpr int P = 8, NH = 36, NR = 3 * P + 6, NS = NH + NR;   // NR = 30 per-lane sums besides the Hessian
     const int bid = (int)blockIdx.x;
