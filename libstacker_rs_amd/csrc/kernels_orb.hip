@@ -302,6 +302,13 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {          // 16-bit circul
     return ((c & (mm >> 8)) & 0xffffu) != 0;
 }
 
+#ifdef STK_FAST_TIMING
+__device__ unsigned long long g_fast_dbg[16];
+#define FAST_TICK(i) do { if (threadIdx.x == 0 && w > 1900 && blockIdx.x == 7 && blockIdx.y == 14 && blockIdx.z == 1) g_fast_dbg[i] = wall_clock64(); } while (0)
+extern "C" void stk_debug_fast_timing(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_dbg), sizeof(g_fast_dbg)); }
+#else
+#define FAST_TICK(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __restrict__ img, int w, int h, int thr, int edge,
                                                              OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs) {
     __shared__ __attribute__((aligned(16))) uint8_t T[FT_TH * FT_TW];
@@ -311,6 +318,7 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
     img += blockIdx.z * bs.pyr; st += blockIdx.z * bs.states; cand += blockIdx.z * bs.cand;
     const int x0 = blockIdx.x * FT_X, y0 = blockIdx.y * FT_Y;
     const int tid = threadIdx.x;
+    FAST_TICK(0);
     if (tid == 0) { nA = 0; nB = 0; }
     for (int i = tid; i < FT_TH * (FT_TW / 4); i += 256) {
         const int ty = i / (FT_TW / 4), d = i - ty * (FT_TW / 4);
@@ -327,6 +335,7 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
     }
     for (int i = tid; i < FT_SH * FT_SW / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
     __syncthreads();
+    FAST_TICK(1);
     // score-region pixel id = sy * FT_SW + sx, sx in [0, 130), sy in [0, 34); image pixel (x0 - 1 + sx, y0 - 1 + sy);
     // its byte in T is at row sy + 3, column sx + 3
     // pass 1: compass pre-test, FOUR pixels per lane. A lane takes one aligned dword of a tile row (4 centre pixels), the
@@ -387,6 +396,7 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
         }
     }
     __syncthreads();
+    FAST_TICK(2);
     // pass 2: ring masks, 9 contiguous
     const int cntA = nA;
     for (int i = tid; i < cntA; i += 256) {
@@ -400,6 +410,7 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
         if (has_arc9(md) || has_arc9(mb)) listB[atomicAdd(&nB, 1)] = (unsigned short)id;
     }
     __syncthreads();
+    FAST_TICK(3);
     // pass 3: strength of the corners
     const int cntB = nB;
     for (int i = tid; i < cntB; i += 256) {
@@ -410,6 +421,10 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
         S[id] = (uint8_t)fast_strength(d, thr);
     }
     __syncthreads();
+    FAST_TICK(4);
+#ifdef STK_FAST_TIMING
+    if (threadIdx.x == 0 && w > 1900 && blockIdx.x == 7 && blockIdx.y == 14 && blockIdx.z == 1) { g_fast_dbg[8] = cntA; g_fast_dbg[9] = cntB; }
+#endif
     // pass 4: strict 3x3 maxima of the interior -> histogram + candidate list (only corners can be maxima: walk list B)
     for (int i = tid; i < cntB; i += 256) {
         const int id = listB[i], sy = id / FT_SW, sx = id - sy * FT_SW;
@@ -426,6 +441,7 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
             if (o < cap) { cand[o].xy = x | (y << 16); cand[o].score = sc; }
         }
     }
+    FAST_TICK(5);
 }
 
 __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, int w, int h, int edge,
