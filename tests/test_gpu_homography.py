@@ -116,3 +116,32 @@ def test_degenerate_inputs(stacker):
     same = np.tile(np.array([[3.0, 4.0]], np.float32), (10, 1))          # all points equal: DLT has no spread
     H0, _ = stacker.find_homography(same, same, 0, 3.0)
     assert H0 is None and oracle.find_homography(same, same, 0, 3.0)[0] is None
+
+
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 63, 64, 65, 129, 1000, 4096])
+def test_problem_sizes_across_wave_boundaries(stacker, n):
+    # one wavefront sweeps a problem in steps of 64 points and keeps its inlier bits in one 64-bit register per lane
+    # (4096 points): the sizes around those boundaries, each against the oracle
+    rng = np.random.default_rng(100 + n)
+    src = rng.uniform(0, 1500, (n, 2)).astype(np.float32)
+    dst = (project(HT, src) + rng.normal(0, 0.4, (n, 2))).astype(np.float32)
+    k = n // 5 if n >= 10 else 0
+    if k:
+        dst[rng.choice(n, k, replace=False)] += rng.uniform(-300, 300, (k, 2)).astype(np.float32)
+    for method in (RANSAC, LMEDS, 0):
+        if method == LMEDS and n == 4:
+            pass                                                       # n == 4: every method takes the single-DLT route
+        H, mask = stacker.find_homography(src, dst, method, 3.0)
+        Ho, masko = oracle.find_homography(src, dst, method, 3.0)
+        assert (H is None) == (Ho is None), (n, method)
+        assert np.array_equal(mask, masko), (n, method)
+        if H is not None:
+            tol = 1e-5 if (method == 0 and k) else 5e-7 if n < 8 else 2e-7   # tiny over-determined fits: weaker curvature
+            assert np.max(np.abs(H - Ho) / np.maximum(np.abs(Ho), 1e-3)) <= tol, (n, method)
+
+
+def test_too_many_points_is_refused(stacker):
+    from libstacker_rs_amd import NotImplementedYet
+    pts = np.random.default_rng(0).uniform(0, 100, (4097, 2)).astype(np.float32)
+    with pytest.raises(NotImplementedYet):
+        stacker.find_homography(pts, pts, RANSAC, 3.0)
