@@ -323,12 +323,17 @@ __global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) 
 #pragma unroll
         for (int u = 0; u < WU; u++) {
             const WarpFrame* fr = a.frames + min(f0 + u, a.n_frames - 1);
-            float X = __builtin_fmaf(fr->M[0], fx, __builtin_fmaf(fr->M[1], fy, fr->M[2]));
-            float Y = __builtin_fmaf(fr->M[3], fx, __builtin_fmaf(fr->M[4], fy, fr->M[5]));
+            // same coordinate arithmetic as the u8 kernel: packed (X, Y), one reciprocal chain shared by X / W and Y / W
+            f32x2 XY = pk_fma(f32x2{fr->M[0], fr->M[3]}, f32x2{fx, fx}, pk_fma(f32x2{fr->M[1], fr->M[4]}, f32x2{fy, fy}, f32x2{fr->M[2], fr->M[5]}));
             if (!AFFINE) {
                 const float W = __builtin_fmaf(fr->M[6], fx, __builtin_fmaf(fr->M[7], fy, fr->M[8]));
-                X = X / W; Y = Y / W;
+                const float aw = __builtin_fabsf(W);
+                const bool safe = (__builtin_fmaxf(__builtin_fmaxf(aw, __builtin_fabsf(XY.x)), __builtin_fabsf(XY.y)) < 1.0995116e12f) &
+                                  (aw > 9.094947e-13f);
+                if (__all(safe)) XY = div2_shared(XY, W);
+                else { XY.x = XY.x / W; XY.y = XY.y / W; }
             }
+            const float X = XY.x, Y = XY.y;
             const bool finite = (__builtin_fabsf(X) < 1e9f) & (__builtin_fabsf(Y) < 1e9f);
             const float flx = __builtin_floorf(X), fly = __builtin_floorf(Y);
             ix[u] = finite ? (int)flx : -100000; iy[u] = finite ? (int)fly : -100000;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) 
 #pragma unroll
             for (int u = 0; u < WU; u++) {
                 const uint8_t* src = (const uint8_t*)a.frames[min(f0 + u, a.n_frames - 1)].src;
-                const unsigned o = (unsigned)(iy[u] * stride_el + ix[u] * 3) * 2u;
+                const unsigned o = (unsigned)(__mul24(iy[u], stride_el) + ix[u] * 3) * 2u;
                 r0[u] = load_tap12(src + o);
                 r1[u] = load_tap12(src + o + (unsigned)stride_el * 2u);
             }
@@ -411,7 +416,7 @@ hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
         return hipGetLastError();
     }
     if (depth == 16 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 && a.sh >= 2 &&
-        a.src_stride * 2 * (size_t)a.sh < ((size_t)1 << 31)) {
+        a.src_stride * 2 * (size_t)a.sh < ((size_t)1 << 31) && a.src_stride < (1u << 23) && a.sh < (1 << 23)) {
         if (a.is_affine) warp_accumulate_u16c3_kernel<true><<<grid, 256, 0, s>>>(a);
         else warp_accumulate_u16c3_kernel<false><<<grid, 256, 0, s>>>(a);
         return hipGetLastError();

@@ -162,14 +162,16 @@ def test_warp_degenerate_matrix_gives_border(stacker):
     assert np.array_equal(got, ref) and not np.isnan(got).any()
 
 
-def test_warp_u8_fast_path_is_bit_identical_to_the_generic_kernel(stacker):
-    """warp_accumulate_u8c3_kernel shares one reciprocal chain between X / W and Y / W (the compiler's own IEEE expansion
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_warp_u8_fast_path_is_bit_identical_to_the_generic_kernel(stacker, dtype):
+    """warp_accumulate_u8c3_kernel (and its 16-bit sibling) shares one reciprocal chain between X / W and Y / W (the compiler's own IEEE expansion
     without the range scaling) and skips clamps and border selects on interior waves: wherever all four taps are inside
     the frame it must return the very bits of the generic kernel (true `/`, per-tap selects), which BORDER_REPLICATE selects."""
     rng = np.random.default_rng(3)
     h, w = 333, 517                                             # not a multiple of the 64 x 4 tile
-    frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
-    ones = np.full((h, w, 3), 255, np.uint8)
+    top = 255 if dtype == np.uint8 else 65535
+    frame = rng.integers(0, top + 1, (h, w, 3)).astype(dtype)
+    ones = np.full((h, w, 3), 255, dtype)
     from libstacker_rs_amd import synth
     mats = [np.eye(3), synth.random_homography(rng, w, h, 8.0), synth.random_homography(rng, w, h, 30.0),
             np.array([[0.7, 0.2, 15.3], [-0.25, 0.9, 40.1], [4e-4, -3e-4, 1.0]]),          # strong perspective: W far from 1
