@@ -222,3 +222,64 @@ def test_hybrid_4k_16bit(stacker):
     # ORB seed shortens ECC at 4K as well
     cold = EP(MotionType.Homography, 200, 1e-5, 5)
     assert sum(s["iterations"] for s in stats[1:]) <= 8 * (n - 1)
+
+
+@pytest.mark.timeout(900)
+def test_config3_256_frames_4k_ecc_match_and_eight_way_shards(stacker):
+    # BASELINE configs[3] at its full size on one GPU: 256 x 3840x2160 BGR u8 (6.4 GB of frames + 8.5 GB of templates),
+    # ecc_match Homography / 5000 / 1e-5 / gauss 5. Every frame against the generator's ground truth; then the stack cut
+    # into the 8 contiguous ranges the 8 GPUs of a node would get (32 frames each, run one after the other on this GPU)
+    # and reduced: per-frame warps bit-identical, image equal up to the order of the f32 adds.
+    n = 256
+    frames, G = synth.make_stack(n, W4K, H4K, device="cuda")
+    out, stats = stacker.ecc_match(frames, ECC, return_stats=True)
+    worst = 0.0
+    for i in range(1, n):
+        assert stats[i]["status"] == 0 and 3 <= stats[i]["iterations"] <= 40
+        worst = max(worst, synth.corner_error(stats[i]["warp"], G[i], W4K, H4K))
+    assert worst <= 0.5, worst
+    total = torch.zeros((H4K, W4K, 3), dtype=torch.float32, device="cuda")
+    added_total = 0
+    for rank in range(8):
+        mine = shard_moving_frames(n, 8, rank)
+        acc = torch.empty_like(total)
+        added, st = stacker.ecc_match_shard(frames[[0] + mine], ECC, rank == 0, acc)
+        for j, g in enumerate(mine):
+            assert np.array_equal(st[1 + j]["warp"], stats[g]["warp"]) and st[1 + j]["iterations"] == stats[g]["iterations"]
+        total += acc
+        added_total += added
+    assert added_total == n
+    assert float((stacker.finalize_mean(total, n) - out).abs().max()) <= 2e-6
+    del frames, total
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(1500)
+def test_config4_1024_frames_4k_16bit_hybrid(stacker):
+    # BASELINE configs[4] at its full size: 1024 x 3840x2160 16-bit BGR (51 GB of frames, 34 GB of templates, ORB in
+    # batches inside a 32 GiB workspace), ORB-seeded ECC refine (an extension beyond the reference).
+    # Size-independent checks: every frame against the generator's ground truth, unit range of the mean, determinism of
+    # a sub-range against the full run (per-frame results do not depend on what else is in the stack).
+    from libstacker_rs_amd import EccMatchParameters as EP
+    n = 1024
+    chunks = []
+    G = []
+    for c0 in range(0, n, 128):                            # generate in chunks: torch.stack of everything would double the footprint
+        f, g = synth.make_stack(0, W4K, H4K, device="cuda", depth=16, indices=list(range(c0, c0 + 128)))
+        chunks.append(f); G.append(g)
+    G = np.concatenate(G)
+    frames = [fr for c in chunks for fr in c.unbind(0)]    # a list of device tensors: not evenly spaced in memory
+    ecc = EP(MotionType.Homography, 200, 1e-5, 5)
+    out, stats = stacker.hybrid_match(frames, KP, ecc, return_stats=True)
+    worst = 0.0
+    for i in range(1, n):
+        assert stats[i]["status"] == 0 and stats[i]["n_inliers"] >= 50
+        worst = max(worst, synth.corner_error(stats[i]["warp"], G[i], W4K, H4K))
+    assert worst <= 0.5, worst
+    assert 0.0 <= float(out.min()) and float(out.max()) <= 1.0 + 1e-6
+    sub = [frames[0]] + frames[700:716]
+    o2, s2 = stacker.hybrid_match(sub, KP, ecc, return_stats=True)
+    for j in range(1, len(sub)):
+        assert np.array_equal(s2[j]["warp"], stats[699 + j]["warp"])
+    del frames, chunks
+    torch.cuda.empty_cache()
