@@ -185,12 +185,12 @@ def main() -> None:
                 agg[k] += t[k]
             if stats is not None:
                 last_stats = stats
-        counts[0] = added
-        counts[1] = dropped
         if world == 1:
             totals[0], totals[1] = added, dropped
             st.finalize_mean(acc, added, out)
             return
+        counts[0] = added
+        counts[1] = dropped
         if pending is not None:                      # its reduce ran under the alignment that just finished
             finish_reduce(pending)
             pending = None

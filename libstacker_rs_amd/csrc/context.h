@@ -38,7 +38,7 @@ struct stk_ctx {
     hipStream_t copy_stream = nullptr;    // host -> HBM copies of host-fed stacks (upload.cpp)
     hipStream_t prep_stream = nullptr;    // grey + blur of frames that arrive while the ECC queue is already running
     std::vector<hipEvent_t> upload_events;
-    hipEvent_t gate_ev = nullptr;
+    hipEvent_t gate_ev = nullptr, gate_ev2 = nullptr;
     int opt_warp_tune = 0;
     int opt_prep_stream = 1;              // 1: templates of a run of frames by the streaming grey+blur kernel in one launch; 0: tiled kernel, frame by frame
     int opt_upload_batch = 8;             // frames per host -> HBM batch

@@ -180,11 +180,17 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
                                   n_frames, PT, ORB_LEVELS, g.cand_total, SELF));
     }
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[7], s));
-    HIP_TRY(hipMemcpyAsync(ws->host_states, st, sizeof(OrbLevelState) * ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, s));
+    // The short lists go to the host on a SECOND stream (the prep stream, idle on this path; not the copy stream, which
+    // may be full of frame uploads), behind an event on the FAST kernels, so that the blur kernels queued next on the
+    // compute stream do not wait behind 8 MB of D2H traffic.
+    hipStream_t ds = ctx->prep_stream;
+    HIP_TRY(hipEventRecord(ctx->gate_ev2, s));
+    HIP_TRY(hipStreamWaitEvent(ds, ctx->gate_ev2, 0));
+    HIP_TRY(hipMemcpyAsync(ws->host_states, st, sizeof(OrbLevelState) * ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, ds));
     // the head of every short list in one strided copy (rows = (frame, level), ORB_PACK of ORB_SEL_CAP entries each)
     HIP_TRY(hipMemcpy2DAsync(ws->host_sel, sizeof(OrbSelected) * ORB_PACK, ws->sel.p, sizeof(OrbSelected) * ORB_SEL_CAP,
-                             sizeof(OrbSelected) * ORB_PACK, (size_t)ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(ctx->gate_ev, s));
+                             sizeof(OrbSelected) * ORB_PACK, (size_t)ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, ds));
+    HIP_TRY(hipEventRecord(ctx->gate_ev, ds));
     // The 7x7 blur of every level (the descriptor stage's input) does not depend on the host's Harris cull: it is queued
     // now and runs while the host works on the short lists (the host waits for the copies above only, not for the stream).
     for (int l = 0; l < ORB_LEVELS; l++)

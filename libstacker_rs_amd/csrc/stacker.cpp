@@ -82,7 +82,8 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
     ctx->stream = ctx->own_stream;
     if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->gate_ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+        hipEventCreateWithFlags(&ctx->gate_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->gate_ev2, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     if (hipHostMalloc((void**)&ctx->host_done, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
@@ -109,6 +110,7 @@ void stk_destroy(stk_ctx* ctx) {
     if (ctx->host_done) (void)hipHostFree(ctx->host_done);
     for (auto& e : ctx->upload_events) if (e) (void)hipEventDestroy(e);
     if (ctx->gate_ev) (void)hipEventDestroy(ctx->gate_ev);
+    if (ctx->gate_ev2) (void)hipEventDestroy(ctx->gate_ev2);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
