@@ -13,8 +13,13 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "context.h"
@@ -315,7 +320,8 @@ int jpeg_load(const std::vector<unsigned char>& file, Pnm& p, std::vector<unsign
     if (!jpeg_sof(file.data(), file.size(), sw, shh, scomp)) return 1;
     if (sw == 0 || shh == 0 || sw > 65500 || shh > 65500) return 1;
     if (scomp != 1 && scomp != 3) return 2;                                 // CMYK / YCCK: left to the caller
-    static int struct_size = 656;                                           // libjpeg-turbo 2.x, v8 ABI, x86-64; corrected by the handshake
+    static std::atomic<int> struct_size_shared{656};                       // libjpeg-turbo 2.x, v8 ABI, x86-64; corrected by the handshake
+    int struct_size = struct_size_shared.load();
     std::vector<unsigned char> store;
     JpegErrorMgr err;
     JpegTrap trap;
@@ -334,6 +340,7 @@ int jpeg_load(const std::vector<unsigned char>& file, Pnm& p, std::vector<unsign
             // JERR_BAD_STRUCT_SIZE is the only error that can arrive before the object exists: msg_parm.i[0] = expected size
             if (!created && attempts < 2 && trap.parm0 > (int)sizeof(JpegDecompressHead) && trap.parm0 < 4096 && trap.parm0 != struct_size) {
                 struct_size = trap.parm0;
+                struct_size_shared.store(struct_size);
                 continue;
             }
             if (created) api.destroy(c);
@@ -407,28 +414,65 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
     return STK_OK;
 }
 
+// The reference decodes inside its Rayon fold (read_grey_and_f32 at lib.rs:200, 756 runs on every worker): files are
+// decoded here by a pool of host threads as well, straight into ONE page-locked block (frame i at i * frame_bytes), so
+// that the host-fed pipeline behind the frame-based entry points moves them by DMA at link rate. Frame 0 is decoded first
+// (it fixes the geometry every other file must match, lib.rs:166).
 template <typename Call>
 stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call call) {
     if (!ctx) return STK_INVALID_PARAMS;
     if (n <= 0 || !paths) return fail(ctx, STK_NOT_ENOUGH_FILES, "Not enough files");      // lib.rs:155-157, 725-727
-    std::vector<std::vector<unsigned char>> pix(n);
-    std::vector<void*> ptrs(n);
     Pnm first;
-    for (int i = 0; i < n; i++) {
-        std::vector<unsigned char> file;
-        Pnm p;
-        stk_status st = load_image(ctx, paths[i], file, p);
-        if (st) return st;
-        if (i == 0) first = p;
-        else if (p.w != first.w || p.h != first.h || p.cn != first.cn || p.depth != first.depth)
-            return fail(ctx, STK_INVALID_PARAMS, std::string("'") + paths[i] + "' differs in size or type from the first frame");
-        if (p.data_ofs == (size_t)-1) pix[i].swap(file);             // PNG: already decoded
-        else {
-            pix[i].resize((size_t)p.w * p.h * p.cn * (p.depth / 8));
-            pnm_decode(file.data() + p.data_ofs, p, pix[i].data());
+    std::vector<unsigned char> file0;
+    stk_status st = load_image(ctx, paths[0], file0, first);
+    if (st) return st;
+    const size_t fbytes = (size_t)first.w * first.h * first.cn * (first.depth / 8);
+    struct Pinned {                       // page-locked when the runtime grants it, plain memory otherwise
+        unsigned char* p = nullptr; bool pinned = false;
+        ~Pinned() { if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); } }
+    } block;
+    if (hipHostMalloc((void**)&block.p, fbytes * (size_t)n, hipHostMallocDefault) == hipSuccess) block.pinned = true;
+    else { (void)hipGetLastError(); block.p = (unsigned char*)std::malloc(fbytes * (size_t)n); }
+    if (!block.p) return fail(ctx, STK_PROCESSING_ERROR, "out of host memory for the decoded stack");
+    auto place = [&](int i, std::vector<unsigned char>& file, const Pnm& p) {
+        unsigned char* dst = block.p + fbytes * (size_t)i;
+        if (p.data_ofs == (size_t)-1) std::memcpy(dst, file.data(), fbytes);             // decoded by a codec library
+        else pnm_decode(file.data() + p.data_ofs, p, dst);
+    };
+    place(0, file0, first);
+    file0.clear(); file0.shrink_to_fit();
+    // frames 1 .. n-1 on a pool of threads; the first failure (lowest index) is the one reported, like a sequential loop
+    const int workers = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, (size_t)std::max(n - 1, 1)});
+    std::atomic<int> next{1};
+    std::mutex em;
+    int err_index = n;
+    stk_status err_status = STK_OK;
+    std::string err_msg;
+    auto work = [&]() {
+        stk_ctx local;                                   // per-thread error text (load_image writes into the context it is given)
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            std::vector<unsigned char> file;
+            Pnm p;
+            stk_status s2 = load_image(&local, paths[i], file, p);
+            if (!s2 && (p.w != first.w || p.h != first.h || p.cn != first.cn || p.depth != first.depth))
+                s2 = fail(&local, STK_INVALID_PARAMS, std::string("'") + paths[i] + "' differs in size or type from the first frame");
+            if (s2) {
+                std::lock_guard<std::mutex> lk(em);
+                if (i < err_index) { err_index = i; err_status = s2; err_msg = local.err; }
+                continue;
+            }
+            place(i, file, p);
         }
-        ptrs[i] = pix[i].data();
-    }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < workers; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (err_status) return fail(ctx, err_status, err_msg);
+    std::vector<void*> ptrs(n);
+    for (int i = 0; i < n; i++) ptrs[i] = block.p + fbytes * (size_t)i;
     stk_frames fr{};
     fr.data = ptrs.data(); fr.n = n; fr.width = first.w; fr.height = first.h; fr.channels = first.cn; fr.depth = first.depth;
     fr.location = STK_HOST; fr.row_stride_bytes = 0;

@@ -16,4 +16,5 @@ hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stub"; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
 }

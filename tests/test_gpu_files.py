@@ -147,3 +147,46 @@ def test_host_fed_pipeline_equals_device_resident(stacker):
         assert all(s["iterations"] == 0 for s in s0) and np.array_equal(s0[1]["warp"], np.eye(3))
     finally:
         stacker.set_option("upload_batch", 8)
+
+
+def test_files_are_decoded_in_parallel_into_pinned_memory(stacker, tmp_path):
+    """*_match_files decodes frames 1..n-1 on a pool of host threads straight into one page-locked block (the reference
+    decodes inside its Rayon fold, lib.rs:200, 756): same image as the frame-based call on the same pixels; with several
+    unreadable files the one reported is the FIRST in list order, whichever thread met it; a JPEG stack (the reference's
+    own data set is JPEG) goes through the same route."""
+    import os, subprocess
+    frames, _ = synth.make_stack(24, 320, 240)
+    fr = frames.numpy()
+    paths = []
+    for i, f in enumerate(fr):
+        paths.append(tmp_path / f"f{i:03d}.ppm")
+        write_pnm(paths[-1], f)
+    ecc = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
+    assert np.array_equal(stacker.ecc_match_files(paths, ecc), stacker.ecc_match(list(fr), ecc))
+    bad = list(paths)
+    bad[17] = tmp_path / "missing_17.ppm"
+    bad[5] = tmp_path / "missing_05.ppm"
+    with pytest.raises(OpenCvError) as ei:
+        stacker.ecc_match_files(bad, ecc)
+    assert "missing_05" in str(ei.value)
+    small = tmp_path / "small.ppm"
+    write_pnm(small, fr[0][:100, :100].copy())
+    with pytest.raises(Exception) as ei:
+        stacker.ecc_match_files(paths[:3] + [small] + paths[3:], ecc)
+    assert "differs in size" in str(ei.value)
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py):
+        return
+    np.save(tmp_path / "stack.npy", fr[:6])
+    code = ("import numpy as np, sys\\nfrom PIL import Image\\nd = sys.argv[1]\\na = np.load(d + '/stack.npy')\\n"
+            "for i, f in enumerate(a):\\n    Image.fromarray(f[..., ::-1]).save(d + '/j%02d.jpg' % i, quality=95, subsampling=0)\\n")
+    if subprocess.run([py, "-c", code, str(tmp_path)]).returncode != 0:
+        return
+    jpaths = [tmp_path / ("j%02d.jpg" % i) for i in range(6)]
+    decoded = [stacker.imread(p) for p in jpaths]
+    assert decoded[0].shape == (240, 320, 3) and np.abs(decoded[1].astype(int) - fr[1].astype(int)).mean() < 3
+    assert np.array_equal(stacker.ecc_match_files(jpaths, ecc), stacker.ecc_match(decoded, ecc))
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    d_f, out_f = stacker.keypoint_match_files(jpaths, kp)
+    d_a, out_a = stacker.keypoint_match(decoded, kp)
+    assert d_f == d_a and np.array_equal(out_f, out_a)
