@@ -98,7 +98,7 @@ def main() -> None:
     W, H, n_global, api = WORKLOADS[args.workload]      # frames in the whole stack (frame 0 = reference)
     scaling = "strong"
     if args.frames_per_gpu > 0:
-        n_global, scaling = args.frames_per_gpu * world, "weak"
+        n_global, scaling = args.frames_per_gpu * (args.gpus if args.single_process else world), "weak"
     ecc_params = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
     kp_params = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)          # examples/main.rs:69-76
     depth = 16 if api == "hybrid" else 8
