@@ -15,10 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(600)
 def test_two_ranks_through_the_shard_entry_points(tmp_path):
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port (the box is shared with nothing, but be polite)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     res = tmp_path / "world2.json"
     env = dict(os.environ, WORLD2_RESULT=str(res), MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29641", os.path.join(ROOT, "tests", "world2_worker.py")]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "world2_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     v = json.loads(res.read_text())
