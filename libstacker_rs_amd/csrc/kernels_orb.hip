@@ -683,6 +683,9 @@ __global__ __launch_bounds__(256) void gauss7_fused_kernel(const uint8_t* __rest
     }
 }
 
+// (A streaming, LDS-free form of this blur — the design of grey_blur_stream_kernel — was built and measured in round 2:
+// 0.26 ms SLOWER per 64 x 1080p batch. Unlike the grey + 5x5 template blur, the 8-bit 7x7 blur is bound by its arithmetic
+// (10 byte conversions and 28 multiply-adds per 4 pixels and row), not by barriers, so the tiled kernel stays.)
 hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s,
                          int n_frames, size_t pyr_stride, size_t tmp_stride) {
     if (w >= 8 && h >= 4 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (pyr_stride & 3) == 0) {

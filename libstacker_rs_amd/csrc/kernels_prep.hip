@@ -90,8 +90,30 @@ __global__ __launch_bounds__(256) void bgr16_to_grey8_kernel(const uint16_t* __r
     out[(size_t)y * w + x] = (uint8_t)(((unsigned)grey_u16(p[0], p[1], p[2]) + 128u) / 257u);
 }
 
+// fast path: four pixels per lane from six aligned dwords (24 bytes), one dword store (rows, frames and outputs 4-byte aligned)
+__global__ __launch_bounds__(256) void bgr16_to_grey8_x4_kernel(const uint16_t* __restrict__ src, size_t stride, int w, int h,
+                                                                uint8_t* __restrict__ out, size_t src_frame_stride, size_t out_frame_stride) {
+    const int q = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (q * 4 >= w) return;
+    src += blockIdx.z * src_frame_stride; out += blockIdx.z * out_frame_stride;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (size_t)y * stride + (size_t)q * 12);
+    uint32_t d[6];                                                   // b0 g0 | r0 b1 | g1 r1 | b2 g2 | r2 b3 | g3 r3 (8-byte aligned)
+    __builtin_memcpy(d, p, 24);
+    const unsigned g0 = ((unsigned)grey_u16(d[0] & 0xffffu, d[0] >> 16, d[1] & 0xffffu) + 128u) / 257u;
+    const unsigned g1 = ((unsigned)grey_u16(d[1] >> 16, d[2] & 0xffffu, d[2] >> 16) + 128u) / 257u;
+    const unsigned g2 = ((unsigned)grey_u16(d[3] & 0xffffu, d[3] >> 16, d[4] & 0xffffu) + 128u) / 257u;
+    const unsigned g3 = ((unsigned)grey_u16(d[4] >> 16, d[5] & 0xffffu, d[5] >> 16) + 128u) / 257u;
+    *reinterpret_cast<uint32_t*>(out + (size_t)y * w + (size_t)q * 4) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+}
+
 hipError_t launch_bgr16_to_grey8(const void* bgr16, int w, int h, size_t stride_bytes, uint8_t* out, hipStream_t s, int n_frames,
                                  size_t src_frame_bytes, size_t out_frame_elems) {
+    if (w % 4 == 0 && stride_bytes % 8 == 0 && src_frame_bytes % 8 == 0 && out_frame_elems % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(bgr16) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        dim3 g4((w / 4 + 255) / 256, h, n_frames);
+        bgr16_to_grey8_x4_kernel<<<g4, 256, 0, s>>>((const uint16_t*)bgr16, stride_bytes / 2, w, h, out, src_frame_bytes / 2, out_frame_elems);
+        return hipGetLastError();
+    }
     dim3 grid((w + 255) / 256, h, n_frames);
     bgr16_to_grey8_kernel<<<grid, 256, 0, s>>>((const uint16_t*)bgr16, stride_bytes / 2, w, h, out, src_frame_bytes / 2, out_frame_elems);
     return hipGetLastError();
