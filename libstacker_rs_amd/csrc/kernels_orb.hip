@@ -309,14 +309,14 @@ extern "C" void stk_debug_fast_timing(unsigned long long* out) { (void)hipMemcpy
 #else
 #define FAST_TICK(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __restrict__ img, int w, int h, int thr, int edge,
-                                                             OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs) {
+__device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ img, int w, int h, int thr, int edge,
+                                                    OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs, int tile_x, int tile_y) {
     __shared__ __attribute__((aligned(16))) uint8_t T[FT_TH * FT_TW];
     __shared__ __attribute__((aligned(16))) uint8_t S[FT_SH * FT_SW];
     __shared__ unsigned short listA[FT_SH * FT_SW], listB[FT_SH * FT_SW];
     __shared__ int nA, nB;
     img += blockIdx.z * bs.pyr; st += blockIdx.z * bs.states; cand += blockIdx.z * bs.cand;
-    const int x0 = blockIdx.x * FT_X, y0 = blockIdx.y * FT_Y;
+    const int x0 = tile_x * FT_X, y0 = tile_y * FT_Y;
     const int tid = threadIdx.x;
     FAST_TICK(0);
     if (tid == 0) { nA = 0; nB = 0; }
@@ -444,6 +444,24 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __re
     FAST_TICK(5);
 }
 
+__global__ __launch_bounds__(256) void fast_nms_tiled_kernel(const uint8_t* __restrict__ img, int w, int h, int thr, int edge,
+                                                             OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs) {
+    fast_nms_tiled_body(img, w, h, thr, edge, st, cand, cap, bs, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// All pyramid levels of a batch in ONE launch: blockIdx.x runs over the tiles of level 0, then level 1, ... (big levels
+// first, so the small ones fill the tail of the launch instead of each leaving most of the chip idle), blockIdx.z = frame.
+__global__ __launch_bounds__(256) void fast_nms_tiled_all_kernel(const uint8_t* __restrict__ pyr, OrbLevelTable L, int thr, int edge,
+                                                                 OrbLevelState* st, OrbCandidate* cand, OrbBatch bs) {
+    const int t = (int)blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < ORB_LEVELS; k++) l += t >= L.tile_ofs[k];
+    const int local = t - L.tile_ofs[l];
+    const int ty = local / L.tiles_x[l], tx = local - ty * L.tiles_x[l];
+    fast_nms_tiled_body(pyr + L.pyr_ofs[l], L.w[l], L.h[l], thr, edge, st + l, cand + L.cand_ofs[l], L.cand_cap[l], bs, tx, ty);
+}
+
 __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, int w, int h, int edge,
                                                        OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63) + edge, y = blockIdx.y * 4 + (threadIdx.x >> 6) + edge;
@@ -463,8 +481,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict
 // (frame, level): lane L owns bins 4 L .. 4 L + 3, an inclusive suffix sum over the lanes gives every bin its count from
 // the top, and the answer is the largest bin whose suffix count reaches `keep` (1 if none does) — what the serial scan
 // from 255 downwards returns.
-__global__ __launch_bounds__(64) void fast_threshold_kernel(OrbLevelState* st, int keep, OrbBatch bs) {
-    st += blockIdx.x * bs.states;
+__device__ __forceinline__ void fast_threshold_body(OrbLevelState* st, int keep) {
     const int lane = threadIdx.x;
     const int4 h4 = *reinterpret_cast<const int4*>(st->hist + 4 * lane);
     const int mine = h4.x + h4.y + h4.z + h4.w;
@@ -486,14 +503,18 @@ __global__ __launch_bounds__(64) void fast_threshold_kernel(OrbLevelState* st, i
         st->n_sel = 0;
     }
 }
+__global__ __launch_bounds__(64) void fast_threshold_kernel(OrbLevelState* st, int keep, OrbBatch bs) {
+    fast_threshold_body(st + blockIdx.x * bs.states, keep);
+}
+__global__ __launch_bounds__(64) void fast_threshold_all_kernel(OrbLevelState* st, OrbLevelTable L, OrbBatch bs) {   // grid (levels, frames)
+    fast_threshold_body(st + blockIdx.y * bs.states + blockIdx.x, L.keep[blockIdx.x]);
+}
 
 // Short list: candidates >= threshold, then the Harris response (blockSize 7, Sobel-like 3x3 on the 8-bit level,
 // integer sums) and the IC moments of each. Two kernels: fast_pick compacts (cheap, one lane per candidate), then
 // fast_describe gives every short-listed corner a whole wavefront — its 49 Harris positions and 31 patch rows are
 // spread over the lanes and reduced with integer adds, which are exact in any order (same values as a serial loop).
-__global__ __launch_bounds__(64) void fast_pick_kernel(OrbLevelState* st, const OrbCandidate* __restrict__ cand, int cap,
-                                                       OrbSelected* sel, int sel_cap, OrbBatch bs) {
-    st += blockIdx.y * bs.states; cand += blockIdx.y * bs.cand; sel += blockIdx.y * bs.sel;
+__device__ __forceinline__ void fast_pick_body(OrbLevelState* st, const OrbCandidate* __restrict__ cand, int cap, OrbSelected* sel, int sel_cap) {
     const int n = min(st->n_cand, cap);
     for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
         const OrbCandidate c = cand[i];
@@ -502,6 +523,16 @@ __global__ __launch_bounds__(64) void fast_pick_kernel(OrbLevelState* st, const 
         if (o < sel_cap) { sel[o].xy = c.xy; sel[o].score = c.score; }
     }
 }
+__global__ __launch_bounds__(64) void fast_pick_kernel(OrbLevelState* st, const OrbCandidate* __restrict__ cand, int cap,
+                                                       OrbSelected* sel, int sel_cap, OrbBatch bs) {
+    fast_pick_body(st + blockIdx.y * bs.states, cand + blockIdx.y * bs.cand, cap, sel + blockIdx.y * bs.sel, sel_cap);
+}
+__global__ __launch_bounds__(64) void fast_pick_all_kernel(OrbLevelState* st, const OrbCandidate* __restrict__ cand, OrbLevelTable L,
+                                                           OrbSelected* sel, int sel_cap, OrbBatch bs) {     // grid (blocks, levels, frames)
+    const int l = blockIdx.y;
+    fast_pick_body(st + blockIdx.z * bs.states + l, cand + blockIdx.z * bs.cand + L.cand_ofs[l], L.cand_cap[l],
+                   sel + blockIdx.z * bs.sel + (size_t)l * sel_cap, sel_cap);
+}
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
@@ -509,9 +540,8 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void fast_describe_kernel(const uint8_t* __restrict__ img, int w, const OrbLevelState* st,
-                                                            OrbSelected* sel, int sel_cap, OrbUmax um, OrbBatch bs) {
-    img += blockIdx.y * bs.pyr; st += blockIdx.y * bs.states; sel += blockIdx.y * bs.sel;
+__device__ __forceinline__ void fast_describe_body(const uint8_t* __restrict__ img, int w, const OrbLevelState* st, OrbSelected* sel,
+                                                   int sel_cap, const OrbUmax& um) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = min(st->n_sel, sel_cap);
     for (int o = blockIdx.x * 4 + wave; o < n; o += gridDim.x * 4) {
@@ -544,6 +574,33 @@ __global__ __launch_bounds__(256) void fast_describe_kernel(const uint8_t* __res
             sel[o].m01 = m01; sel[o].m10 = m10;
         }
     }
+}
+__global__ __launch_bounds__(256) void fast_describe_kernel(const uint8_t* __restrict__ img, int w, const OrbLevelState* st,
+                                                            OrbSelected* sel, int sel_cap, OrbUmax um, OrbBatch bs) {
+    fast_describe_body(img + blockIdx.y * bs.pyr, w, st + blockIdx.y * bs.states, sel + blockIdx.y * bs.sel, sel_cap, um);
+}
+__global__ __launch_bounds__(256) void fast_describe_all_kernel(const uint8_t* __restrict__ pyr, OrbLevelTable L, const OrbLevelState* st,
+                                                                OrbSelected* sel, int sel_cap, OrbUmax um, OrbBatch bs) {   // grid (blocks, levels, frames)
+    const int l = blockIdx.y;
+    fast_describe_body(pyr + blockIdx.z * bs.pyr + L.pyr_ofs[l], L.w[l], st + blockIdx.z * bs.states + l,
+                       sel + blockIdx.z * bs.sel + (size_t)l * sel_cap, sel_cap, um);
+}
+
+// FAST + short list of ALL levels of a batch in four launches (instead of four per level). Returns hipErrorNotSupported when
+// a level does not qualify for the tiled kernel (tiny or unaligned levels): the caller then goes level by level.
+hipError_t launch_fast_all(const uint8_t* pyr, const OrbLevelTable& L, int thr, int edge, OrbLevelState* st, OrbCandidate* cand,
+                           OrbSelected* sel, int sel_cap, const OrbUmax& um, hipStream_t s, int n_frames, size_t pyr_stride,
+                           size_t states_stride, size_t cand_stride, size_t sel_stride) {
+    const OrbBatch bs{pyr_stride, states_stride, cand_stride, sel_stride};
+    if ((reinterpret_cast<uintptr_t>(pyr) & 3) != 0 || (pyr_stride & 3) != 0) return hipErrorNotSupported;
+    for (int l = 0; l < ORB_LEVELS; l++)
+        if (L.w[l] < 16 || L.h[l] < 8 || (L.pyr_ofs[l] & 3) != 0) return hipErrorNotSupported;
+    if (L.tile_ofs[ORB_LEVELS] > 0)
+        fast_nms_tiled_all_kernel<<<dim3(L.tile_ofs[ORB_LEVELS], 1, n_frames), 256, 0, s>>>(pyr, L, thr, edge, st, cand, bs);
+    fast_threshold_all_kernel<<<dim3(ORB_LEVELS, n_frames), 64, 0, s>>>(st, L, bs);
+    fast_pick_all_kernel<<<dim3(64, ORB_LEVELS, n_frames), 64, 0, s>>>(st, cand, L, sel, sel_cap, bs);
+    fast_describe_all_kernel<<<dim3(32, ORB_LEVELS, n_frames), 256, 0, s>>>(pyr, L, st, sel, sel_cap, um, bs);
+    return hipGetLastError();
 }
 
 hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,

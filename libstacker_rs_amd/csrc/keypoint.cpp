@@ -169,11 +169,31 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
                                     n_frames, PT));
     const bool timed = ctx->opt_profile >= 1;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[6], s));
+    // FAST + NMS + short list: all levels in four launches when every level qualifies for the tiled kernel, else level by level
+    OrbLevelTable L{};
+    bool all_ok = g.pyr.total < ((size_t)1 << 32) && g.cand_total < ((size_t)1 << 32);
+    L.tile_ofs[0] = 0;
+    for (int l = 0; l < ORB_LEVELS; l++) {
+        const int lw = g.pyr.w[l], lh = g.pyr.h[l];
+        L.w[l] = lw; L.h[l] = lh; L.pyr_ofs[l] = (unsigned)g.pyr.ofs[l]; L.cand_ofs[l] = (unsigned)g.cand_ofs[l];
+        L.cand_cap[l] = (int)g.cand_cap[l]; L.keep[l] = 2 * g.nfeatures[l];
+        L.tiles_x[l] = std::max(1, (lw + 127) / 128);
+        const bool has_interior = lw > 2 * ORB_EDGE && lh > 2 * ORB_EDGE;      // otherwise runByImageBorder leaves nothing
+        L.tile_ofs[l + 1] = L.tile_ofs[l] + (has_interior ? L.tiles_x[l] * ((lh + 31) / 32) : 0);
+        if (lw <= 6 || lh <= 6) all_ok = false;
+    }
+    hipError_t fe = hipErrorNotSupported;
+    if (all_ok) {
+        fe = launch_fast_all(pyr, L, ORB_FAST_THRESHOLD, ORB_EDGE, st, ws->cand.as<OrbCandidate>(), ws->sel.as<OrbSelected>(), ORB_SEL_CAP,
+                             g.umax, s, n_frames, PT, ORB_LEVELS, g.cand_total, SELF);
+        if (fe != hipSuccess && fe != hipErrorNotSupported) return fail(ctx, STK_HIP_ERROR, std::string("FAST: ") + hipGetErrorString(fe));
+    }
     for (int l = 0; l < ORB_LEVELS; l++) {
         const int lw = g.pyr.w[l], lh = g.pyr.h[l];
         if (lw <= 6 || lh <= 6) continue;
         ctx->timing.fast_launches += 1;
         ctx->timing.fast_pixels += (int64_t)lw * lh * n_frames;
+        if (fe == hipSuccess) continue;
         HIP_TRY(launch_fast_level(pyr + g.pyr.ofs[l], lw, lh, ORB_FAST_THRESHOLD, ORB_EDGE, 2 * g.nfeatures[l], score + g.pyr.ofs[l],
                                   st + l, ws->cand.as<OrbCandidate>() + g.cand_ofs[l], (int)g.cand_cap[l],
                                   ws->sel.as<OrbSelected>() + (size_t)l * ORB_SEL_CAP, ORB_SEL_CAP, g.umax, s,

@@ -16,6 +16,12 @@ struct OrbLevelState { int hist[256]; int n_cand; int threshold; int n_sel; int 
 struct OrbUmax { int u[16]; };
 struct Gauss7 { float k[7]; };
 struct OrbPyramid { int w[ORB_LEVELS], h[ORB_LEVELS]; size_t ofs[ORB_LEVELS]; size_t total; };
+// per-level geometry of a pyramid for the all-levels launches: tiles of the FAST kernel (128 x 32 px) in level order
+struct OrbLevelTable {
+    int w[ORB_LEVELS], h[ORB_LEVELS], tiles_x[ORB_LEVELS], tile_ofs[ORB_LEVELS + 1];
+    unsigned pyr_ofs[ORB_LEVELS], cand_ofs[ORB_LEVELS];
+    int cand_cap[ORB_LEVELS], keep[ORB_LEVELS];
+};
 struct OrbFinalKeypoint { int level, cx, cy; float cos_a, sin_a; int frame, row; };   // row: descriptor row to write
 
 struct KeypointWorkspace;
@@ -38,6 +44,9 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
                              OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,
                              const OrbUmax& um, hipStream_t s, int n_frames = 1, size_t pyr_stride = 0,
                              size_t states_stride = 0, size_t cand_stride = 0, size_t sel_stride = 0);
+hipError_t launch_fast_all(const uint8_t* pyr, const OrbLevelTable& L, int thr, int edge, OrbLevelState* st, OrbCandidate* cand,
+                           OrbSelected* sel, int sel_cap, const OrbUmax& um, hipStream_t s, int n_frames, size_t pyr_stride,
+                           size_t states_stride, size_t cand_stride, size_t sel_stride);
 hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s,
                          int n_frames = 1, size_t pyr_stride = 0, size_t tmp_stride = 0);
 hipError_t upload_orb_pattern(const signed char* p);
