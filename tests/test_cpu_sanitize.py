@@ -90,6 +90,15 @@ def test_host_pool_under_tsan(tmp_path):
 
 
 @pytest.mark.timeout(600)
+def test_async_upload_under_tsan(tmp_path):
+    exe = str(tmp_path / "upload_tsan")
+    _build("upload_tsan.cpp", exe, ["-fsanitize=thread"])
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), timeout=500)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-500:] + r.stderr[-3000:]
+    assert "WARNING: ThreadSanitizer" not in r.stderr
+
+
+@pytest.mark.timeout(600)
 def test_ransac_host_half_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "ransac_host")
     _build("ransac_host_harness.cpp", exe, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])
