@@ -3,8 +3,9 @@
 //
 // A helper thread enqueues the copies on the context's copy stream (batch 0 = the reference frame alone, then `batch`
 // frames each) and records one event per batch. Frames in pinned memory (stk_host_alloc, hipHostMalloc, hipHostRegister)
-// go by DMA at PCIe rate; pageable frames are staged by the HIP runtime, which blocks the enqueuing thread — the reason
-// the enqueuing happens off the caller's thread. Consumers make their stream wait for the batch they need.
+// go by DMA at PCIe rate; for pageable frames the HIP runtime locks or stages the source and may block the enqueuing
+// thread — the reason the enqueuing happens off the caller's thread (25 MB malloc'ed frames measured the same 55 GB/s).
+// Consumers make their stream wait for the batch they need.
 #pragma once
 #include <condition_variable>
 #include <mutex>
