@@ -1,5 +1,6 @@
 // context.h — the engine's per-GPU context (stk_ctx) and host helpers shared by stacker.cpp and keypoint.cpp.
 #pragma once
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +33,10 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value);
 int multi_member_count(const stk_ctx* ctx);
 stk_ctx* multi_member(const stk_ctx* ctx, int i);
 
+// Frames that are still being produced (decoded) while the engine already runs: the uploader asks the gate before it
+// copies a frame. `wait` blocks until the frame at `ptr` is complete and returns false if it never will be.
+struct FrameGate { std::function<bool(const void* ptr)> wait; };
+
 struct stk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -39,6 +44,7 @@ struct stk_ctx {
     hipStream_t prep_stream = nullptr;    // grey + blur of frames that arrive while the ECC queue is already running
     std::vector<hipEvent_t> upload_events;
     hipEvent_t gate_ev = nullptr, gate_ev2 = nullptr;
+    const FrameGate* frame_gate = nullptr;   // set by the path-based entry points for the duration of one call
     int opt_warp_tune = 0;
     int opt_prep_stream = 1;              // 1: templates of a run of frames by the streaming grey+blur kernel in one launch; 0: tiled kernel, frame by frame
     int opt_upload_batch = 8;             // frames per host -> HBM batch

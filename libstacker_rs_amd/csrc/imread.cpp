@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -441,10 +442,15 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
     };
     place(0, file0, first);
     file0.clear(); file0.shrink_to_fit();
-    // frames 1 .. n-1 on a pool of threads; the first failure (lowest index) is the one reported, like a sequential loop
+    // Frames 1 .. n-1 on a pool of threads WHILE the engine already runs: the call below starts at once, its uploader asks
+    // the gate before it copies a frame (AsyncUpload), so decode, PCIe transfer, template preparation and alignment of
+    // different frames overlap. The first failure (lowest index) is the one reported, like a sequential loop.
     const int workers = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, (size_t)std::max(n - 1, 1)});
     std::atomic<int> next{1};
     std::mutex em;
+    std::condition_variable ecv;
+    std::vector<char> state(n, 0);                       // 0 pending, 1 decoded, 2 failed (guarded by em)
+    state[0] = 1;
     int err_index = n;
     stk_status err_status = STK_OK;
     std::string err_msg;
@@ -458,25 +464,35 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
             stk_status s2 = load_image(&local, paths[i], file, p);
             if (!s2 && (p.w != first.w || p.h != first.h || p.cn != first.cn || p.depth != first.depth))
                 s2 = fail(&local, STK_INVALID_PARAMS, std::string("'") + paths[i] + "' differs in size or type from the first frame");
-            if (s2) {
+            if (!s2) place(i, file, p);
+            {
                 std::lock_guard<std::mutex> lk(em);
-                if (i < err_index) { err_index = i; err_status = s2; err_msg = local.err; }
-                continue;
+                state[i] = s2 ? 2 : 1;
+                if (s2 && i < err_index) { err_index = i; err_status = s2; err_msg = local.err; }
             }
-            place(i, file, p);
+            ecv.notify_all();
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < workers; t++) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
-    if (err_status) return fail(ctx, err_status, err_msg);
+    for (int t = 0; t < workers; t++) pool.emplace_back(work);
+    FrameGate gate;
+    gate.wait = [&](const void* ptr) -> bool {
+        const size_t i = ((const unsigned char*)ptr - block.p) / fbytes;
+        std::unique_lock<std::mutex> lk(em);
+        ecv.wait(lk, [&]() { return state[i] != 0 || err_status != STK_OK; });
+        return state[i] == 1;
+    };
     std::vector<void*> ptrs(n);
     for (int i = 0; i < n; i++) ptrs[i] = block.p + fbytes * (size_t)i;
     stk_frames fr{};
     fr.data = ptrs.data(); fr.n = n; fr.width = first.w; fr.height = first.h; fr.channels = first.cn; fr.depth = first.depth;
     fr.location = STK_HOST; fr.row_stride_bytes = 0;
-    return call(&fr);
+    ctx->frame_gate = &gate;
+    st = call(&fr);
+    ctx->frame_gate = nullptr;
+    for (auto& t : pool) t.join();
+    if (err_status) return fail(ctx, err_status, err_msg);   // a file that could not be decoded outranks whatever the engine made of it
+    return st;
 }
 
 }  // namespace

@@ -119,6 +119,12 @@ stk_status multi_match(stk_ctx* ctx, int kind, const stk_frames* frames, const s
     auto body = [&](int r) {
         stk_ctx* c = ms->members[r];
         (void)hipSetDevice(ms->devices[r]);
+        // frames that are still being decoded (path-based entry points): every member asks the caller's gate
+        struct GateLoan {
+            stk_ctx* member;
+            GateLoan(stk_ctx* m, const FrameGate* g) : member(m) { if (member) member->frame_gate = g; }
+            ~GateLoan() { if (member) member->frame_gate = nullptr; }
+        } loan(r > 0 ? c : nullptr, ctx->frame_gate);
         int first, count;
         shard_range(n, world, r, first, count);
         std::vector<const void*> ptrs(1 + count);

@@ -22,12 +22,14 @@ stk_status AsyncUpload::start(stk_ctx* ctx, const stk_frames* frames, void* dst_
     std::vector<const void*> src(frames->data, frames->data + n_frames_);
     const int device = ctx->device;
     hipStream_t cs = ctx->copy_stream;
-    thread_ = std::thread([this, src, dst_base, device, cs]() {
+    const FrameGate* gate = ctx->frame_gate;
+    thread_ = std::thread([this, src, dst_base, device, cs, gate]() {
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipEventRecord(t0_, cs);
         for (int b = 0; b < batches(); b++) {
             for (int k = 0; k < count_[b] && e == hipSuccess; k++) {
                 const int i = first_[b] + k;
+                if (gate && !gate->wait(src[i])) { e = hipErrorInvalidValue; break; }      // the producer (a decoder) failed
                 e = hipMemcpyAsync((uint8_t*)dst_base + frame_bytes_ * (size_t)i, src[i], frame_bytes_, hipMemcpyHostToDevice, cs);
             }
             if (e == hipSuccess) e = hipEventRecord(events_[b], cs);

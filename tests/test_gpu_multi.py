@@ -86,3 +86,20 @@ def test_bound_and_unbound_contexts_side_by_side(stacker):
             assert np.array_equal(a.cpu().numpy(), ref) and np.array_equal(b.cpu().numpy(), ref) and np.array_equal(c.cpu().numpy(), ref)
     finally:
         bound.close()
+
+
+def test_multi_context_on_files(stacker, multi, tmp_path):
+    # the path-based entry point on a multi-device context: frames are still being decoded by the thread pool when the
+    # members' uploaders ask for them (one gate shared by every member)
+    frames, _ = synth.make_stack(13, 320, 240)
+    paths = []
+    for i, f in enumerate(frames.numpy()):
+        p = tmp_path / f"m{i:02d}.ppm"
+        p.write_bytes(b"P6\n320 240\n255\n" + np.ascontiguousarray(f[..., ::-1]).tobytes())
+        paths.append(p)
+    one = stacker.ecc_match_files(paths, ECC)
+    two = multi.ecc_match_files(paths, ECC)
+    assert np.max(np.abs(one - two)) <= 1e-6
+    d1, k1 = stacker.keypoint_match_files(paths, KP)
+    d2, k2 = multi.keypoint_match_files(paths, KP)
+    assert d1 == d2 and np.max(np.abs(k1 - k2)) <= 1e-6
