@@ -87,6 +87,7 @@ struct EccIterArgs {
     double* sums;                // [all slots][ECC_MAX_SUMS]: the reduced sums, stage 1 -> stage 2 of the solve kernel
     int* tickets;                // [all slots]: arrival counter of the solve kernel's stage-1 workgroups (self-resetting)
     int slot0;                   // first slot of this launch (0: all slots in one launch)
+    int units_q, units_r;        // column-walking pass: (column strip, row) units per wave and the remainder (set by launch_ecc_iter)
 };
 
 struct WarpFrame {
@@ -130,6 +131,7 @@ hipError_t launch_grey_blur_batch(const void* const* ptrs_dev, const void* base,
 hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
                              int ref_stride, hipStream_t s);
 // variant: 3 = production kernels, 0 = direct cross-check version
+hipError_t launch_ecc_iter_h8c(const EccIterArgs& a, hipStream_t s);   // kernels_ecc_h8c.hip; a.units_q / units_r set
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s);
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
                             EccFrameResult* results, hipStream_t s, const float* init_warps = nullptr);

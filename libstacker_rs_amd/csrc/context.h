@@ -56,7 +56,7 @@ struct stk_ctx {
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
-    int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = production (row-factorised Hessian / pipelined affine family), 0 = direct cross-check
+    int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = production (column-walking homography pass / pipelined affine family), 0 = direct cross-check
     stk_timing timing{};
     hipEvent_t ev[8] = {};
     hipEvent_t poll_ev[2] = {};

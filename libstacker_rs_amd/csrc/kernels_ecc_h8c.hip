@@ -1,0 +1,326 @@
+// kernels_ecc_h8c.hip — the column-walking iteration pass of findTransformECC for homographies (lib.rs:769-777;
+// algorithm SURVEY.md 8a-E*). Same 66 moment sums and the same partials layout as the kernels in kernels_ecc.hip.
+// Compiled with -fno-slp-vectorize (Makefile): every pair is written out as float2 here, and the vectoriser's own
+// pairings cost register shuffles.
+#include "ecc_pixel.h"
+#include <type_traits>
+
+namespace stk {
+
+#ifndef STK_H8_WG
+#define STK_H8_WG 4
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// The row-walking pass this one replaced ran ~97 VALU instructions per pixel (95 in the loop, the rest in row-end and
+// block-end reductions) with the VALU pipe saturated. What this version removes, all of it arithmetic:
+//   * A wave owns a COLUMN strip — 64 adjacent x, a run of consecutive rows — so X is a per-lane constant and Y a
+//     scalar: X never enters the loop. The lane accumulates Y-moments (sum q, sum q*Y, sum q*Y^2 with scalar
+//     multipliers) and the powers of X are applied once, when the strip is flushed. The template address is a scalar
+//     base plus a constant lane offset (no per-pixel address arithmetic), the loop counters live in SGPRs.
+//   * J.u, J.v, J.m are factorised the same way: J = (a, b, t) (x) (X, Y, 1), so a lane keeps sum c*w and sum c*w*Y for
+//     c in {a, b, t}, w in {u, v, m}: 18 accumulators instead of 24, no J vector at all.
+//   * Everything that comes in pairs is written as v_pk_* on float2: (gx, gy) bilinear (vertical blend first, so the
+//     two taps of a row pair up as loaded), (ja, jb), the six products, all accumulators.
+//   * A strip whose four corners map well inside the frame-0 image (the image of a convex set under a homography with
+//     w > 0 is convex) takes a loop without the mask: no compares, no selects, no clamps — bit-identical results to
+//     the masked loop, because with m = 1 every masked expression reduces to the unmasked one exactly.
+//   * ONE cross-lane reduction per strip instead of one per row plus one per block: 66 per-lane values go through a
+//     lane-transposing fold (each level halves the number of registers: v_permlane32_swap / v_permlane16_swap for lane
+//     bits 5 and 4, DPP row_ror / quad_perm and ds_swizzle below), ~200 instructions instead of ~460 + 2 x 144.
+// ~60 VALU instructions per pixel in the unmasked loop. Work units are (column strip, row) pairs in column-major order,
+// split evenly over the 4 x nb waves of the frame, so a frame's summation partition still depends on its size only
+// (shard-invariant bits). What limits it now, and what was tried on top: DESIGN.md 4.1.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+__device__ __forceinline__ f32x2 bc2(float v) { return f32x2{v, v}; }
+// a product the vectoriser must not pair up by shuffling its operands into new register pairs (two moves more than
+// the two multiplies it saves): the results land in adjacent registers and feed v_pk_* directly
+__device__ __forceinline__ float mul_opaque(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// the compiler's own builtins for these two drop the second result (ROCm 7.2: r[0] + r[1] comes out as r[0] + r[0]),
+// hence inline assembly; the s_nop covers the VALU-write -> permlane-swap-read hazard the assembler cannot see.
+// v_permlane32_swap a, b: a' = {a[0:31], b[0:31]}, b' = {a[32:63], b[32:63]}; permlane16: the same per pair of 16-lane rows.
+__device__ __forceinline__ void lane_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// One level of the fold over lane bit BIT: of two registers, the lanes with the bit clear keep `lo`, those with it
+// set keep `hi`, each adding its partner's copy of the same register. Afterwards a lane holds one of the two sums.
+template <int BIT>
+__device__ __forceinline__ float fold_pair(float lo, float hi, bool bit) {
+    if constexpr (BIT == 5) { lane_swap32(lo, hi); return lo + hi; }
+    else if constexpr (BIT == 4) { lane_swap16(lo, hi); return lo + hi; }
+    else {
+        const float keep = bit ? hi : lo, send = bit ? lo : hi;
+        if constexpr (BIT == 3) return keep + dpp_move<0x128>(send);                                              // row_ror:8
+        else if constexpr (BIT == 2) return keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x101F));   // lane ^ 4
+        else if constexpr (BIT == 1) return keep + dpp_move<0x4E>(send);                                          // quad_perm [2,3,0,1]
+        else return keep + dpp_move<0xB1>(send);                                                                   // quad_perm [1,0,3,2]
+    }
+}
+// v[0 .. N): per-lane values. Returns with v[0] (and v[1] for N > 64) holding the 64-lane total of value
+// k = 64 * r + bitreverse6(lane): six levels, n -> ceil(n / 2) registers each, order of additions fixed.
+template <int N>
+__device__ __forceinline__ void lane_transpose_sum(float (&v)[N], int lane) {
+    static_assert(N <= 128, "two result registers at most");
+    constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2, n6 = (n5 + 1) / 2;
+#pragma unroll
+    for (int o = 0; o < n1; o++) v[o] = fold_pair<5>(v[2 * o], 2 * o + 1 < N ? v[2 * o + 1] : 0.f, lane & 32);
+#pragma unroll
+    for (int o = 0; o < n2; o++) v[o] = fold_pair<4>(v[2 * o], 2 * o + 1 < n1 ? v[2 * o + 1] : 0.f, lane & 16);
+#pragma unroll
+    for (int o = 0; o < n3; o++) v[o] = fold_pair<3>(v[2 * o], 2 * o + 1 < n2 ? v[2 * o + 1] : 0.f, lane & 8);
+#pragma unroll
+    for (int o = 0; o < n4; o++) v[o] = fold_pair<2>(v[2 * o], 2 * o + 1 < n3 ? v[2 * o + 1] : 0.f, lane & 4);
+#pragma unroll
+    for (int o = 0; o < n5; o++) v[o] = fold_pair<1>(v[2 * o], 2 * o + 1 < n4 ? v[2 * o + 1] : 0.f, lane & 2);
+#pragma unroll
+    for (int o = 0; o < n6; o++) v[o] = fold_pair<0>(v[2 * o], 2 * o + 1 < n5 ? v[2 * o + 1] : 0.f, lane & 1);
+}
+
+// one tap row of a pixel: I at (ix, ix + 1) and (gx, gy) at (ix, ix + 1)
+struct H8cTaps {
+    f32x2_a4 i;
+    f32x4_a8 g;
+};
+// a row in flight besides its taps: source coordinate, its fractional part, 1/w, the template sample
+struct H8cRow {
+    f32x2 s, frac;
+    float rw, tval;
+};
+struct H8cBlend {              // the bilinear samples of a pixel: I, (gx, gy)
+    float Iw;
+    f32x2 gw;
+};
+
+__global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArgs a) {
+    constexpr int MOTION = STK_MOTION_HOMOGRAPHY;
+    constexpr int P = 8, NH = 36, NS = NH + 3 * P + 6;
+    const int bid = (int)blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int slot = a.slot0 + q % a.n_slots;
+    const int region = (q / a.n_slots) * 8 + xcd;
+    const EccSlot* sl = a.slots + slot;
+    const int frame = sl->frame;
+    if (frame < 0) return;
+    SlotConst c;
+    load_slot_const(sl, a, c);
+    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+
+    const int rs = a.ref.stride;
+    const int corner = REF_PAD * rs + REF_PAD;
+    const char* __restrict__ Ib = reinterpret_cast<const char*>(a.ref.I - corner);
+    const char* __restrict__ Gb = reinterpret_cast<const char*>(a.ref.gxy - 2 * (size_t)corner);
+    const char* __restrict__ Ib1 = Ib + (size_t)rs * 4;
+    const char* __restrict__ Gb1 = Gb + (size_t)rs * 8;
+
+    // accumulators of the current strip (f32, per lane)
+    f32x2 hq[3][3];                  // [products (aa,bb) (at,bt) (ab,tt)][power of Y]
+    f32x2 m0ab[3], m1ab[3];          // (a.w, b.w) for w = u, v, m; m1: times Y
+    f32x2 m0t, m1t;                  // (t.u, t.v)
+    float m0tm, m1tm;                // t.m
+    float s_mf, s_x;                 // sum m, sum um.v
+    f32x2 s_uv, s_sq;                // (sum um, sum v), (sum um.u, sum v.v)
+    auto clear = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            hq[k][0] = hq[k][1] = hq[k][2] = bc2(0.f);
+            m0ab[k] = m1ab[k] = bc2(0.f);
+        }
+        m0t = m1t = s_uv = s_sq = bc2(0.f);
+        m0tm = m1tm = s_mf = s_x = 0.f;
+    };
+    clear();
+    double dacc0 = 0.0, dacc1 = 0.0;  // lane L: totals of sum number bitreverse6(L) and 64 + bitreverse6(L)
+
+    // this wave's run of (column, row) units, column-major
+    const int g = region * 4 + wave;
+    int u = g * a.units_q + min(g, a.units_r);
+    const int uend = u + a.units_q + (g < a.units_r ? 1 : 0);
+    while (u < uend) {
+        const int col = u / a.th;
+        const int y0 = u - col * a.th;
+        const int y1 = min(a.th, y0 + (uend - u));
+        u += y1 - y0;
+        const int x = col * 64 + lane;
+        const bool active = x < a.tw;
+        const int xc = min(x, a.tw - 1);
+        unsigned xoff = (unsigned)xc << 2;
+        const float fx = (float)xc;
+        const f32x2 colXY = pk_fma(f32x2{c.m0, c.m3}, bc2(fx), f32x2{c.m2, c.m5});
+        const float colW = __builtin_fmaf(c.m6, fx, c.m8);    // m22 == 1 is guaranteed by the launcher (den == w)
+
+        // all four corners of the strip at least 0.05 px inside [0, W-1] x [0, H-1] and w >= 1/4 there:
+        // every pixel of the strip is inside the mask and no tap leaves the image
+        bool fast = col * 64 + 63 < a.tw;
+        {
+            const float cx[2] = {(float)(col * 64), (float)(col * 64 + 63)}, cy[2] = {(float)y0, (float)(y1 - 1)};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float X = __builtin_fmaf(c.m1, cy[k >> 1], __builtin_fmaf(c.m0, cx[k & 1], c.m2));
+                const float Y = __builtin_fmaf(c.m4, cy[k >> 1], __builtin_fmaf(c.m3, cx[k & 1], c.m5));
+                const float W = __builtin_fmaf(c.m7, cy[k >> 1], __builtin_fmaf(c.m6, cx[k & 1], c.m8));
+                const float r = __builtin_amdgcn_rcpf(W);
+                const float px = X * r, py = Y * r;
+                fast = fast & (W >= 0.25f) & (px >= 0.05f) & (px <= c.mxw - 0.05f) & (py >= 0.05f) & (py <= c.mxh - 0.05f);
+            }
+        }
+        fast = __builtin_amdgcn_readfirstlane((int)fast) != 0;
+
+        auto run = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            // source coordinate of this lane's pixel in row y: (sx, sy), 1/w, floor
+            auto coords = [&](float fy, f32x2& sxy, float& rw, f32x2& fl) {
+                const f32x2 XY = pk_fma(f32x2{c.m1, c.m4}, bc2(fy), colXY);
+                rw = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m7, fy, colW));
+                sxy = XY * bc2(rw);                           // hatX = -X'/den and hatY = -Y'/den are exactly -sx, -sy (den == w)
+                fl = f32x2{__builtin_floorf(sxy.x), __builtin_floorf(sxy.y)};
+            };
+            // Stage A of row y: coordinates, then the loads of the template sample and the 2 x 2 taps of the three planes
+            // (five load instructions; what was tried instead is listed in DESIGN.md 4.1).
+            auto issue = [&](int y, H8cRow& co, H8cTaps& top, H8cTaps& bot) {
+                const int yc = min(y, y1 - 1);                 // past the strip end: a harmless repeat, never used
+                asm volatile("" : "+v"(xoff));                 // keeps (row base) + (lane offset) in the saddr + voffset form
+                co.tval = *(const float*)((const char*)(T + (size_t)yc * a.templ_row_stride) + xoff);
+                f32x2 fl;
+                coords((float)yc, co.s, co.rw, fl);
+                co.frac = co.s - fl;
+                if constexpr (!FAST) {
+                    // clamp into the zero border with one v_med3_f32 each; NaN -> -2 (all taps zero)
+                    fl = f32x2{__builtin_amdgcn_fmed3f(fl.x, -2.0f, c.fiw), __builtin_amdgcn_fmed3f(fl.y, -2.0f, c.fih)};
+                }
+                const int ix = (int)fl.x, iy = (int)fl.y;
+                const unsigned bo = (unsigned)(__mul24(iy, rs) + ix + corner) << 2;     // byte offset of the upper-left tap in the I plane
+                top.i = *(const f32x2_a4*)(Ib + bo); bot.i = *(const f32x2_a4*)(Ib1 + bo);
+                top.g = *(const f32x4_a8*)(Gb + 2u * bo); bot.g = *(const f32x4_a8*)(Gb1 + 2u * bo);
+            };
+            auto blend = [&](const H8cRow& co, const H8cTaps& top, const H8cTaps& bot, H8cBlend& bl) {
+                const float ax = co.frac.x, ay = co.frac.y;
+                // bilinear taps, the vertical blend first: the two taps of a row are adjacent in memory, so the
+                // row pairs go through v_pk_* as loaded
+                const f32x2 i0 = top.i, i1 = bot.i;
+                const f32x2 iv = pk_fma(bc2(ay), i1 - i0, i0);
+                bl.Iw = __builtin_fmaf(ax, iv.y - iv.x, iv.x);
+                f32x2 g0a = top.g.lo, g0b = top.g.hi, g1a = bot.g.lo, g1b = bot.g.hi;
+                asm("" : "+v"(g0a), "+v"(g0b));                // (the compiler would re-join the halves and subtract four scalars)
+                const f32x2 vl = pk_fma(bc2(ay), g1a - g0a, g0a), vr = pk_fma(bc2(ay), g1b - g0b, g0b);
+                bl.gw = pk_fma(bc2(ax), vr - vl, vl);                   // (gxw, gyw)
+            };
+            auto accumulate = [&](const H8cRow& co, const H8cBlend& bl, int y) {
+                if constexpr (!FAST) { if (!active) return; }
+                // (Y, Y^2) as a real register pair: a broadcast half-pair would leave its other half to the register
+                // allocator, and when that is the target of a load in flight the compiler waits for the load
+                const float fy = (float)y;
+                f32x2 fyv = {fy, fy * fy};
+                asm("" : "+v"(fyv));
+                const f32x2 FY = bc2(fyv.x), FYY = bc2(fyv.y);
+                const f32x2 sxy = co.s;
+                const float rw = co.rw, Iw = bl.Iw;
+                const f32x2 gw = bl.gw;
+                const f32x2 jab = gw * bc2(rw);                       // (ja, jb)
+                const f32x2 sj = sxy * jab;
+                const f32x2 JT = -sj - f32x2{sj.y, sj.x};               // hatX*ja + hatY*jb, in both halves
+                const float jt = JT.x;
+                const f32x2 P0 = jab * jab, P1 = jab * JT, P2 = {mul_opaque(jab.x, jab.y), mul_opaque(jt, jt)};
+                hq[0][0] += P0; hq[0][1] = pk_fma(P0, FY, hq[0][1]); hq[0][2] = pk_fma(P0, FYY, hq[0][2]);
+                hq[1][0] += P1; hq[1][1] = pk_fma(P1, FY, hq[1][1]); hq[1][2] = pk_fma(P1, FYY, hq[1][2]);
+                hq[2][0] += P2; hq[2][1] = pk_fma(P2, FY, hq[2][1]); hq[2][2] = pk_fma(P2, FYY, hq[2][2]);
+                const f32x2 cuv = f32x2{Iw, co.tval} - f32x2{c.cI, c.cT};   // centred samples
+                f32x2 uv, umv, Am;
+                float tm;
+                if constexpr (FAST) { uv = cuv; umv = cuv; Am = jab; tm = jt; }
+                else {
+                    const float sx = sxy.x, sy = sxy.y;
+                    bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
+                    if (!inside) {
+                        const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
+                        inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
+                        const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
+                                          (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
+                        if (edge) inside = nearest_inside_exact<MOTION>(x, y, sl->warp, c.iw, c.ih);
+                    }
+                    const float mf = inside ? 1.0f : 0.0f;
+                    uv = f32x2{inside ? cuv.x : Iw, inside ? cuv.y : 0.0f};
+                    umv = f32x2{uv.x * mf, uv.y};
+                    Am = jab * bc2(mf); tm = jt * mf;
+                    s_mf += mf;
+                }
+                const f32x2 Au = jab * bc2(uv.x), Av = jab * bc2(uv.y), Tuv = JT * uv;
+                m0ab[0] += Au; m0ab[1] += Av; m0ab[2] += Am; m0t += Tuv; m0tm += tm;
+                m1ab[0] = pk_fma(Au, FY, m1ab[0]); m1ab[1] = pk_fma(Av, FY, m1ab[1]); m1ab[2] = pk_fma(Am, FY, m1ab[2]);
+                m1t = pk_fma(Tuv, FY, m1t); m1tm = __builtin_fmaf(tm, fy, m1tm);
+                s_uv += umv; s_sq = pk_fma(umv, uv, s_sq); s_x = __builtin_fmaf(umv.x, uv.y, s_x);
+            };
+            // Two rows in flight: the loads of row y+1 are issued before the arithmetic of row y.
+            H8cTaps ta, tb, ua, ub;
+            H8cRow ca, cb;
+            H8cBlend bl;
+            issue(y0, ca, ta, ua);
+            for (int y = y0; y < y1; y += 2) {
+                issue(y + 1, cb, tb, ub);
+                blend(ca, ta, ua, bl); accumulate(ca, bl, y);
+                issue(y + 2, ca, ta, ua);
+                if (y + 1 < y1) { blend(cb, tb, ub, bl); accumulate(cb, bl, y + 1); }
+            }
+            if constexpr (FAST) s_mf += (float)(y1 - y0);
+        };
+        if (fast) run(std::true_type{}); else run(std::false_type{});
+
+        // flush the strip: apply the powers of X, sum over the 64 lanes, add to the f64 totals
+        {
+            float v[NS];
+            const float fxx = fx * fx;
+            int idx = 0;
+#pragma unroll
+            for (int i = 0; i < P; i++)
+#pragma unroll
+                for (int j = i; j < P; j++) {
+                    const int ci = i < 6 ? i % 3 : i - 6, cj = j < 6 ? j % 3 : j - 6;      // 0 a, 1 b, 2 t
+                    const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
+                    // (aa,bb) -> hq[0], (at,bt) -> hq[1], (ab,tt) -> hq[2]
+                    const int reg = lo == hi ? (lo == 2 ? 2 : 0) : (hi == 2 ? 1 : 2);
+                    const int half = lo == hi ? (lo == 0 ? 0 : 1) : (hi == 2 ? lo : 0);
+                    const int xpow = (i < 3) + (j < 3), ypow = (i >= 3 && i < 6) + (j >= 3 && j < 6);
+                    const float m = hq[reg][ypow][half];
+                    v[idx++] = xpow == 0 ? m : xpow == 1 ? m * fx : m * fxx;
+                }
+#pragma unroll
+            for (int w = 0; w < 3; w++)
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    const int ci = i < 6 ? i % 3 : i - 6;
+                    const float z0 = ci == 2 ? (w == 2 ? m0tm : m0t[w]) : m0ab[w][ci];
+                    const float z1 = ci == 2 ? (w == 2 ? m1tm : m1t[w]) : m1ab[w][ci];
+                    v[NH + w * P + i] = i < 3 ? z0 * fx : i < 6 ? z1 : z0;
+                }
+            v[NH + 3 * P + 0] = s_mf; v[NH + 3 * P + 1] = s_uv.x; v[NH + 3 * P + 2] = s_sq.x;
+            v[NH + 3 * P + 3] = s_uv.y; v[NH + 3 * P + 4] = s_sq.y; v[NH + 3 * P + 5] = s_x;
+            lane_transpose_sum<NS>(v, lane);
+            dacc0 += (double)v[0]; dacc1 += (double)v[1];
+            clear();
+        }
+    }
+
+    __shared__ double red[4][NS];
+    const int k0 = (int)(__builtin_bitreverse32((unsigned)lane) >> 26);
+    red[wave][k0] = dacc0;
+    if (k0 + 64 < NS) red[wave][k0 + 64] = dacc1;
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        const int k = threadIdx.x;
+        const double s = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+        a.partials[((size_t)slot * NS + k) * a.nb + region] = s;   // [slot][sum][block]
+    }
+}
+
+hipError_t launch_ecc_iter_h8c(const EccIterArgs& a, hipStream_t s) {
+    ecc_iter_h8c_kernel<<<a.nb * a.n_slots, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace stk

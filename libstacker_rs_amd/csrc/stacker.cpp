@@ -779,7 +779,7 @@ stk_status stk_find_transform_ecc(stk_ctx* ctx, const void* templ, const void* i
         stk_ctx* c; int saved;
         ~VariantGuard() { c->opt_ecc_variant = saved; }
     } guard{ctx, ctx->opt_ecc_variant};
-    if (guard.saved == 3 && params->motion_type == STK_MOTION_HOMOGRAPHY && warp[8] != 1.0f) ctx->opt_ecc_variant = 0;
+    if (guard.saved != 0 && params->motion_type == STK_MOTION_HOMOGRAPHY && warp[8] != 1.0f) ctx->opt_ecc_variant = 0;
     st = ecc_plan(ctx, width, height, 1, params->motion_type, pl);
     if (st) return st;
     const size_t rb = (size_t)width * (depth / 8);
