@@ -168,6 +168,8 @@ void        stk_host_free(void* p);
  *                        value changes the f32 summation partition, i.e. results at round-off level (within the stated
  *                        ECC tolerance)
  *   "ecc_variant"        ECC pixel-pass kernel: 3 production (default), 0 the direct cross-check version
+ *   "ecc_ring"           homography pass: 1 (default) frame-0 rows go through a per-wave LDS ring where a strip allows it,
+ *                        0 every tap is gathered from global memory; the results are bit-identical
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
  *   "kp_workers"         host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
  *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table

@@ -87,6 +87,7 @@ struct EccIterArgs {
     double* sums;                // [all slots][ECC_MAX_SUMS]: the reduced sums, stage 1 -> stage 2 of the solve kernel
     int* tickets;                // [all slots]: arrival counter of the solve kernel's stage-1 workgroups (self-resetting)
     int slot0;                   // first slot of this launch (0: all slots in one launch)
+    int ring;                    // column-walking pass: 1 = frame-0 rows through the per-wave LDS ring where a strip allows it (option ecc_ring)
     int units_q, units_r;        // column-walking pass: (column strip, row) units per wave and the remainder (set by launch_ecc_iter)
 };
 

@@ -56,6 +56,7 @@ struct stk_ctx {
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
+    int opt_ecc_ring = 1;         // column-walking ECC pass: frame-0 rows through the per-wave LDS ring (0: always gather from global memory)
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = production (column-walking homography pass / pipelined affine family), 0 = direct cross-check
     stk_timing timing{};
     hipEvent_t ev[8] = {};

@@ -32,6 +32,9 @@ namespace stk {
 // split evenly over the 4 x nb waves of the frame, so a frame's summation partition still depends on its size only
 // (shard-invariant bits). What limits it now, and what was tried on top: DESIGN.md 4.1.
 // ---------------------------------------------------------------------------------------------------
+// (the LDS-DMA blocks below set m0 and say so in their clobber lists; clang warns that m0 is a reserved register)
+#pragma clang diagnostic ignored "-Winline-asm"
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 __device__ __forceinline__ f32x2 bc2(float v) { return f32x2{v, v}; }
@@ -92,6 +95,17 @@ struct H8cRow {
     f32x2 s, frac;
     float rw, tval;
 };
+// The per-wave LDS ring of frame-0 rows (see run_ring in the kernel): LK + 1 slots of LW pixels — LW floats of I, then
+// LW (gx, gy) pairs — and a small ring of template rows. 4 waves x 9 232 B = 36.9 KB per workgroup, four workgroups per CU.
+constexpr int LW = 76;                        // window width in pixels (64 + the spread of a strip's source columns)
+constexpr int LROW = LW * 12;                 // bytes per slot
+constexpr int LG = LW * 4;                    // offset of the (gx, gy) pairs inside a slot
+constexpr int LK = 8;                         // rows in the ring (a power of two); slot LK duplicates slot 0's successor role
+constexpr int LT = 4;                         // template rows in flight
+constexpr int LWAVE = (LK + 1) * LROW + LT * 256;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
 struct H8cBlend {              // the bilinear samples of a pixel: I, (gx, gy)
     float Iw;
     f32x2 gw;
@@ -111,6 +125,8 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
     load_slot_const(sl, a, c);
     const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) char ring_all[4 * LWAVE];
+    char* const ring = ring_all + wave * LWAVE;          // this wave's ring; nothing in it is shared between waves
 
     const int rs = a.ref.stride;
     const int corner = REF_PAD * rs + REF_PAD;
@@ -158,6 +174,7 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
         // all four corners of the strip at least 0.05 px inside [0, W-1] x [0, H-1] and w >= 1/4 there:
         // every pixel of the strip is inside the mask and no tap leaves the image
         bool fast = col * 64 + 63 < a.tw;
+        float cpx[4], cpy[4];                                   // source coordinates of the corners (x0,y0) (x63,y0) (x0,yl) (x63,yl)
         {
             const float cx[2] = {(float)(col * 64), (float)(col * 64 + 63)}, cy[2] = {(float)y0, (float)(y1 - 1)};
 #pragma unroll
@@ -167,20 +184,93 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 const float W = __builtin_fmaf(c.m7, cy[k >> 1], __builtin_fmaf(c.m6, cx[k & 1], c.m8));
                 const float r = __builtin_amdgcn_rcpf(W);
                 const float px = X * r, py = Y * r;
+                cpx[k] = px; cpy[k] = py;
                 fast = fast & (W >= 0.25f) & (px >= 0.05f) & (px <= c.mxw - 0.05f) & (py >= 0.05f) & (py <= c.mxh - 0.05f);
             }
         }
         fast = __builtin_amdgcn_readfirstlane((int)fast) != 0;
+        // The ring path needs more: the strip's source columns inside a window of LW pixels, the source row rising by
+        // 0.6 .. 1.4 per template row (at most two new rows per step, three rows of lookahead suffice) and differing by
+        // at most 2.5 rows across the 64 lanes (the ring holds LK rows).
+        const float sxmin = __builtin_fminf(__builtin_fminf(cpx[0], cpx[1]), __builtin_fminf(cpx[2], cpx[3]));
+        const float sxmax = __builtin_fmaxf(__builtin_fmaxf(cpx[0], cpx[1]), __builtin_fmaxf(cpx[2], cpx[3]));
+        const int xb = __builtin_amdgcn_readfirstlane(((int)__builtin_floorf(sxmin) - 1) & ~3);   // window origin, 16-byte aligned
+        bool ringable = fast & (a.ring != 0) & ((int)__builtin_floorf(sxmax) + 2 - xb <= LW - 1) &
+                        (__builtin_fabsf(cpy[1] - cpy[0]) <= 2.5f) & (__builtin_fabsf(cpy[3] - cpy[2]) <= 2.5f);
+        {
+            const float n = (float)(y1 - 1 - y0);
+            const float d0 = cpy[2] - cpy[0], d1 = cpy[3] - cpy[1];
+            ringable = ringable & (y1 - y0 >= 8) & (d0 >= 0.6f * n) & (d0 <= 1.4f * n) & (d1 >= 0.6f * n) & (d1 <= 1.4f * n);
+        }
+        ringable = __builtin_amdgcn_readfirstlane((int)ringable) != 0;
 
+        // source coordinate of this lane's pixel in row y: (sx, sy), 1/w, floor
+        auto coords = [&](float fy, f32x2& sxy, float& rw, f32x2& fl) {
+            const f32x2 XY = pk_fma(f32x2{c.m1, c.m4}, bc2(fy), colXY);
+            rw = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m7, fy, colW));
+            sxy = XY * bc2(rw);                           // hatX = -X'/den and hatY = -Y'/den are exactly -sx, -sy (den == w)
+            fl = f32x2{__builtin_floorf(sxy.x), __builtin_floorf(sxy.y)};
+        };
+        auto blend = [&](const H8cRow& co, const H8cTaps& top, const H8cTaps& bot, H8cBlend& bl) {
+            const float ax = co.frac.x, ay = co.frac.y;
+            // bilinear taps, the vertical blend first: the two taps of a row are adjacent in memory, so the
+            // row pairs go through v_pk_* as loaded
+            const f32x2 i0 = top.i, i1 = bot.i;
+            const f32x2 iv = pk_fma(bc2(ay), i1 - i0, i0);
+            bl.Iw = __builtin_fmaf(ax, iv.y - iv.x, iv.x);
+            f32x2 g0a = top.g.lo, g0b = top.g.hi, g1a = bot.g.lo, g1b = bot.g.hi;
+            asm("" : "+v"(g0a), "+v"(g0b));                // (the compiler would re-join the halves and subtract four scalars)
+            const f32x2 vl = pk_fma(bc2(ay), g1a - g0a, g0a), vr = pk_fma(bc2(ay), g1b - g0b, g0b);
+            bl.gw = pk_fma(bc2(ax), vr - vl, vl);                   // (gxw, gyw)
+        };
+        auto accumulate = [&](auto fast_tag, const H8cRow& co, const H8cBlend& bl, int y) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            if constexpr (!FAST) { if (!active) return; }
+            // (Y, Y^2) as a real register pair: a broadcast half-pair would leave its other half to the register
+            // allocator, and when that is the target of a load in flight the compiler waits for the load
+            const float fy = (float)y;
+            f32x2 fyv = {fy, fy * fy};
+            asm("" : "+v"(fyv));
+            const f32x2 FY = bc2(fyv.x), FYY = bc2(fyv.y);
+            const f32x2 sxy = co.s;
+            const float rw = co.rw, Iw = bl.Iw;
+            const f32x2 gw = bl.gw;
+            const f32x2 jab = gw * bc2(rw);                       // (ja, jb)
+            const f32x2 sj = sxy * jab;
+            const f32x2 JT = -sj - f32x2{sj.y, sj.x};               // hatX*ja + hatY*jb, in both halves
+            const float jt = JT.x;
+            const f32x2 P0 = jab * jab, P1 = jab * JT, P2 = {mul_opaque(jab.x, jab.y), mul_opaque(jt, jt)};
+            hq[0][0] += P0; hq[0][1] = pk_fma(P0, FY, hq[0][1]); hq[0][2] = pk_fma(P0, FYY, hq[0][2]);
+            hq[1][0] += P1; hq[1][1] = pk_fma(P1, FY, hq[1][1]); hq[1][2] = pk_fma(P1, FYY, hq[1][2]);
+            hq[2][0] += P2; hq[2][1] = pk_fma(P2, FY, hq[2][1]); hq[2][2] = pk_fma(P2, FYY, hq[2][2]);
+            const f32x2 cuv = f32x2{Iw, co.tval} - f32x2{c.cI, c.cT};   // centred samples
+            f32x2 uv, umv, Am;
+            float tm;
+            if constexpr (FAST) { uv = cuv; umv = cuv; Am = jab; tm = jt; }
+            else {
+                const float sx = sxy.x, sy = sxy.y;
+                bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
+                if (!inside) {
+                    const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
+                    inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
+                    const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
+                                      (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
+                    if (edge) inside = nearest_inside_exact<MOTION>(x, y, sl->warp, c.iw, c.ih);
+                }
+                const float mf = inside ? 1.0f : 0.0f;
+                uv = f32x2{inside ? cuv.x : Iw, inside ? cuv.y : 0.0f};
+                umv = f32x2{uv.x * mf, uv.y};
+                Am = jab * bc2(mf); tm = jt * mf;
+                s_mf += mf;
+            }
+            const f32x2 Au = jab * bc2(uv.x), Av = jab * bc2(uv.y), Tuv = JT * uv;
+            m0ab[0] += Au; m0ab[1] += Av; m0ab[2] += Am; m0t += Tuv; m0tm += tm;
+            m1ab[0] = pk_fma(Au, FY, m1ab[0]); m1ab[1] = pk_fma(Av, FY, m1ab[1]); m1ab[2] = pk_fma(Am, FY, m1ab[2]);
+            m1t = pk_fma(Tuv, FY, m1t); m1tm = __builtin_fmaf(tm, fy, m1tm);
+            s_uv += umv; s_sq = pk_fma(umv, uv, s_sq); s_x = __builtin_fmaf(umv.x, uv.y, s_x);
+        };
         auto run = [&](auto fast_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
-            // source coordinate of this lane's pixel in row y: (sx, sy), 1/w, floor
-            auto coords = [&](float fy, f32x2& sxy, float& rw, f32x2& fl) {
-                const f32x2 XY = pk_fma(f32x2{c.m1, c.m4}, bc2(fy), colXY);
-                rw = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m7, fy, colW));
-                sxy = XY * bc2(rw);                           // hatX = -X'/den and hatY = -Y'/den are exactly -sx, -sy (den == w)
-                fl = f32x2{__builtin_floorf(sxy.x), __builtin_floorf(sxy.y)};
-            };
             // Stage A of row y: coordinates, then the loads of the template sample and the 2 x 2 taps of the three planes
             // (five load instructions; what was tried instead is listed in DESIGN.md 4.1).
             auto issue = [&](int y, H8cRow& co, H8cTaps& top, H8cTaps& bot) {
@@ -199,63 +289,6 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 top.i = *(const f32x2_a4*)(Ib + bo); bot.i = *(const f32x2_a4*)(Ib1 + bo);
                 top.g = *(const f32x4_a8*)(Gb + 2u * bo); bot.g = *(const f32x4_a8*)(Gb1 + 2u * bo);
             };
-            auto blend = [&](const H8cRow& co, const H8cTaps& top, const H8cTaps& bot, H8cBlend& bl) {
-                const float ax = co.frac.x, ay = co.frac.y;
-                // bilinear taps, the vertical blend first: the two taps of a row are adjacent in memory, so the
-                // row pairs go through v_pk_* as loaded
-                const f32x2 i0 = top.i, i1 = bot.i;
-                const f32x2 iv = pk_fma(bc2(ay), i1 - i0, i0);
-                bl.Iw = __builtin_fmaf(ax, iv.y - iv.x, iv.x);
-                f32x2 g0a = top.g.lo, g0b = top.g.hi, g1a = bot.g.lo, g1b = bot.g.hi;
-                asm("" : "+v"(g0a), "+v"(g0b));                // (the compiler would re-join the halves and subtract four scalars)
-                const f32x2 vl = pk_fma(bc2(ay), g1a - g0a, g0a), vr = pk_fma(bc2(ay), g1b - g0b, g0b);
-                bl.gw = pk_fma(bc2(ax), vr - vl, vl);                   // (gxw, gyw)
-            };
-            auto accumulate = [&](const H8cRow& co, const H8cBlend& bl, int y) {
-                if constexpr (!FAST) { if (!active) return; }
-                // (Y, Y^2) as a real register pair: a broadcast half-pair would leave its other half to the register
-                // allocator, and when that is the target of a load in flight the compiler waits for the load
-                const float fy = (float)y;
-                f32x2 fyv = {fy, fy * fy};
-                asm("" : "+v"(fyv));
-                const f32x2 FY = bc2(fyv.x), FYY = bc2(fyv.y);
-                const f32x2 sxy = co.s;
-                const float rw = co.rw, Iw = bl.Iw;
-                const f32x2 gw = bl.gw;
-                const f32x2 jab = gw * bc2(rw);                       // (ja, jb)
-                const f32x2 sj = sxy * jab;
-                const f32x2 JT = -sj - f32x2{sj.y, sj.x};               // hatX*ja + hatY*jb, in both halves
-                const float jt = JT.x;
-                const f32x2 P0 = jab * jab, P1 = jab * JT, P2 = {mul_opaque(jab.x, jab.y), mul_opaque(jt, jt)};
-                hq[0][0] += P0; hq[0][1] = pk_fma(P0, FY, hq[0][1]); hq[0][2] = pk_fma(P0, FYY, hq[0][2]);
-                hq[1][0] += P1; hq[1][1] = pk_fma(P1, FY, hq[1][1]); hq[1][2] = pk_fma(P1, FYY, hq[1][2]);
-                hq[2][0] += P2; hq[2][1] = pk_fma(P2, FY, hq[2][1]); hq[2][2] = pk_fma(P2, FYY, hq[2][2]);
-                const f32x2 cuv = f32x2{Iw, co.tval} - f32x2{c.cI, c.cT};   // centred samples
-                f32x2 uv, umv, Am;
-                float tm;
-                if constexpr (FAST) { uv = cuv; umv = cuv; Am = jab; tm = jt; }
-                else {
-                    const float sx = sxy.x, sy = sxy.y;
-                    bool inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
-                    if (!inside) {
-                        const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
-                        inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
-                        const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
-                                          (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
-                        if (edge) inside = nearest_inside_exact<MOTION>(x, y, sl->warp, c.iw, c.ih);
-                    }
-                    const float mf = inside ? 1.0f : 0.0f;
-                    uv = f32x2{inside ? cuv.x : Iw, inside ? cuv.y : 0.0f};
-                    umv = f32x2{uv.x * mf, uv.y};
-                    Am = jab * bc2(mf); tm = jt * mf;
-                    s_mf += mf;
-                }
-                const f32x2 Au = jab * bc2(uv.x), Av = jab * bc2(uv.y), Tuv = JT * uv;
-                m0ab[0] += Au; m0ab[1] += Av; m0ab[2] += Am; m0t += Tuv; m0tm += tm;
-                m1ab[0] = pk_fma(Au, FY, m1ab[0]); m1ab[1] = pk_fma(Av, FY, m1ab[1]); m1ab[2] = pk_fma(Am, FY, m1ab[2]);
-                m1t = pk_fma(Tuv, FY, m1t); m1tm = __builtin_fmaf(tm, fy, m1tm);
-                s_uv += umv; s_sq = pk_fma(umv, uv, s_sq); s_x = __builtin_fmaf(umv.x, uv.y, s_x);
-            };
             // Two rows in flight: the loads of row y+1 are issued before the arithmetic of row y.
             H8cTaps ta, tb, ua, ub;
             H8cRow ca, cb;
@@ -263,13 +296,136 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             issue(y0, ca, ta, ua);
             for (int y = y0; y < y1; y += 2) {
                 issue(y + 1, cb, tb, ub);
-                blend(ca, ta, ua, bl); accumulate(ca, bl, y);
+                blend(ca, ta, ua, bl); accumulate(fast_tag, ca, bl, y);
                 issue(y + 2, ca, ta, ua);
-                if (y + 1 < y1) { blend(cb, tb, ub, bl); accumulate(cb, bl, y + 1); }
+                if (y + 1 < y1) { blend(cb, tb, ub, bl); accumulate(fast_tag, cb, bl, y + 1); }
             }
             if constexpr (FAST) s_mf += (float)(y1 - y0);
         };
-        if (fast) run(std::true_type{}); else run(std::false_type{});
+        // ---- frame-0 rows through a per-wave LDS ring ----
+        // The loop above is bound by the L1's tag pipeline: the 2 x 2 taps of a wave are overlapping 8- and 16-byte
+        // pieces, 81 tag look-ups per row of 64 pixels against one look-up per clock (TCP_TOTAL_CACHE_ACCESSES, DESIGN.md
+        // 4.1). Here every frame-0 row segment the strip needs is fetched ONCE, as aligned 16-byte pieces, by LDS-DMA
+        // (global_load_lds_dwordx4: no registers held while in flight) into a ring of LK rows private to the wave — no
+        // barrier anywhere — and the taps are ds_read2 with per-lane addresses; the template sample comes the same way
+        // through a four-row ring. ~20 tag look-ups per row instead of 81.
+        // Pipeline per template row y: wait for the DMA issued one step ago (the template's two steps ago) -> coordinates
+        // and tap reads of row y+1 -> DMA of the frame-0 rows row y+2 will need and of template row y+3 -> arithmetic
+        // of row y.
+        auto run_ring = [&]() {
+            const float* const gI = a.ref.I + xb;
+            const float* const gG = a.ref.gxy + 2 * (ptrdiff_t)xb;
+            const unsigned l16 = (unsigned)lane * 16u;
+            const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;   // the ring's LDS byte address
+            // LDS-DMA in inline assembly (m0 = LDS address of the wave's first lane, 16 or 4 bytes per lane): the builtin makes
+            // the compiler wait for EVERY outstanding transfer before any LDS read, which caps the prefetch at one row.
+            // Here the waits are explicit (wait_keep); the "memory" clobber and the ring operand keep the LDS reads on
+            // their side of each transfer and wait. The loader's state is a handful of running scalars (next row's
+            // global addresses, its slot), because the scalar unit is shared by the CU's four SIMDs and every
+            // instruction of this bookkeeping competes with the other waves' (65 scalar instructions per row in the
+            // first version: the scalar unit was 72 % busy).
+            const char* pI = nullptr;                            // frame-0 row loaded + 1: I at column xb, (gx, gy) at column xb
+            const char* pG = nullptr;
+            unsigned dst = ring_lds;                             // LDS address of slot (loaded + 1) % LK
+            int issued = 0;                                      // transfers issued in the current step
+            int loaded = 0;                                      // last frame-0 row in the ring (or on its way)
+            const unsigned long long lanesI = (1ull << (LW / 4)) - 1, lanesG = (1ull << (LW / 2)) - 1;
+            auto dma_row = [&]() {                               // the next frame-0 row, columns xb .. xb + LW - 1, into its slot
+                unsigned long long saved;
+                if (dst == ring_lds) {                           // slot 0 ... and behind the last slot, so that "the row below" is always the next slot
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                                 "s_add_u32 m0, %1, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                                 "s_mov_b64 exec, %3\n\ts_add_u32 m0, %1, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+                                 "s_add_u32 m0, %1, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(saved) : "s"(dst), "s"(lanesI), "s"(lanesG), "v"(l16), "s"(pI), "s"(pG),
+                                   "n"(LK * LROW), "n"(LG), "n"(LK * LROW + LG), "r"(ring) : "memory", "m0", "scc");
+                    issued += 4;
+                } else {
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                                 "s_mov_b64 exec, %3\n\ts_add_u32 m0, %1, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(saved) : "s"(dst), "s"(lanesI), "s"(lanesG), "v"(l16), "s"(pI), "s"(pG), "n"(LG), "r"(ring)
+                                 : "memory", "m0", "scc");
+                    issued += 2;
+                }
+                pI += (size_t)rs * 4; pG += (size_t)rs * 8;
+                dst = dst + LROW == ring_lds + LK * LROW ? ring_lds : dst + LROW;
+                loaded++;
+            };
+            const char* pT = nullptr;                            // template row of the next dma_templ, this strip's first column
+            unsigned dstT = ring_lds + (LK + 1) * LROW;
+            int yT = 0;
+            auto dma_templ = [&]() {                             // the next template row (the last one repeats), this lane's pixel
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                             : : "s"(dstT), "v"(xoff), "s"(pT), "r"(ring) : "memory", "m0");
+                issued += 1;
+                if (yT < y1 - 1) pT += (size_t)a.templ_row_stride * 4;
+                yT++;
+                dstT = ring_lds + (LK + 1) * LROW + (unsigned)(yT & (LT - 1)) * 256u;
+            };
+            // wait until only the `keep` newest transfers are in flight (they complete in order); keep is 1 + 2 * rows (+ 2)
+            auto wait_keep = [&](int keep) {
+                if (keep & 4) { if (keep & 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+                else { if (keep & 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+            };
+            // coordinates of row y, its taps and template sample out of the ring; returns the lanes' extreme source rows
+            auto fetch = [&](int y, H8cRow& co, H8cTaps& top, H8cTaps& bot, int& ilo, int& ihi) {
+                const int yc = min(y, y1 - 1);
+                f32x2 fl;
+                coords((float)yc, co.s, co.rw, fl);
+                co.frac = co.s - fl;
+                const int ix = (int)fl.x, iy = (int)fl.y;
+                const int i0 = __builtin_amdgcn_readlane(iy, 0), i1 = __builtin_amdgcn_readlane(iy, 63);
+                ilo = min(i0, i1); ihi = max(i0, i1);
+                const int so = __mul24(iy & (LK - 1), LROW), dx = ix - xb;
+                const float* const pi = (const float*)(ring + so + dx * 4);
+                const f32x2_a4* const pg = (const f32x2_a4*)(ring + so + LG + dx * 8);
+                top.i = f32x2_a4{pi[0], pi[1]}; bot.i = f32x2_a4{pi[LROW / 4], pi[LROW / 4 + 1]};
+                top.g.lo = pg[0]; top.g.hi = pg[1]; bot.g.lo = pg[LROW / 8]; bot.g.hi = pg[LROW / 8 + 1];
+                co.tval = ((const float*)(ring + (LK + 1) * LROW + (yc & (LT - 1)) * 256))[lane];
+            };
+            H8cTaps ta, ua, tb, ub;
+            H8cRow ca, cb;
+            H8cBlend bl;
+            int ilo, ihi;
+            {   // fill: the rows of the first template row plus the lookahead, three template rows
+                f32x2 s0, fl0; float rw0;
+                coords((float)y0, s0, rw0, fl0);
+                const int iy = (int)fl0.y;
+                const int i0 = __builtin_amdgcn_readlane(iy, 0), i1 = __builtin_amdgcn_readlane(iy, 63);
+                loaded = min(i0, i1) - 1;
+                pI = (const char*)(gI + (ptrdiff_t)(loaded + 1) * rs); pG = (const char*)(gG + 2 * (ptrdiff_t)(loaded + 1) * rs);
+                dst = ring_lds + (unsigned)((loaded + 1) & (LK - 1)) * LROW;
+                const int want = max(i0, i1) + 4;
+                while (loaded < want) dma_row();
+                pT = (const char*)(T + (size_t)y0 * a.templ_row_stride); yT = y0;
+                dstT = ring_lds + (LK + 1) * LROW + (unsigned)(yT & (LT - 1)) * 256u;
+                dma_templ(); dma_templ(); dma_templ();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                fetch(y0, ca, ta, ua, ilo, ihi);
+            }
+            // A transfer issued in step y has landed when step y+2 starts (wait_keep leaves only step y+1's in flight),
+            // so step y fetches what row y+3 will read: frame-0 rows up to ihi(y+1) + 4 (the source row rises by at most
+            // 1.4 per template row) and template row y+3. Nothing a later fetch needs is overwritten: the rows in flight
+            // reach back to ihi(y+1) - 4 at most, the lanes of a row differ by at most 3.
+            int prev_issued = 1;                                 // (nothing is in flight before the first step)
+            auto step = [&](H8cRow& cur, H8cTaps& tcur, H8cTaps& ucur, H8cRow& nxt, H8cTaps& tnxt, H8cTaps& unxt, int y) {
+                wait_keep(prev_issued);
+                fetch(y + 1, nxt, tnxt, unxt, ilo, ihi);
+                issued = 0;
+                if (loaded < ihi + 4) dma_row();
+                if (loaded < ihi + 4) dma_row();
+                dma_templ();
+                prev_issued = issued;
+                blend(cur, tcur, ucur, bl); accumulate(std::true_type{}, cur, bl, y);
+            };
+            for (int y = y0; y < y1; y += 2) {
+                step(ca, ta, ua, cb, tb, ub, y);
+                if (y + 1 < y1) step(cb, tb, ub, ca, ta, ua, y + 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in the ring after the strip (it is reused)
+            s_mf += (float)(y1 - y0);
+        };
+        if (ringable) run_ring(); else if (fast) run(std::true_type{}); else run(std::false_type{});
 
         // flush the strip: apply the powers of X, sum over the 64 lanes, add to the f64 totals
         {

@@ -155,6 +155,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
+    else if (n == "ecc_ring") ctx->opt_ecc_ring = value != 0;
     else if (n == "ecc_variant") { if (value != 0 && value != 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 3 (production) or 0 (direct cross-check)"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
@@ -263,6 +264,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     a.slots = ctx->slots.as<EccSlot>();
     a.n_slots = pl.n_slots;
     a.nb = pl.nb;
+    a.ring = ctx->opt_ecc_ring;
     a.partials = ctx->partials.as<double>();
     a.sums = a.partials + (size_t)pl.n_slots * pl.nb * pl.nsums;
     a.tickets = reinterpret_cast<int*>(a.sums + (size_t)pl.n_slots * ECC_MAX_SUMS);

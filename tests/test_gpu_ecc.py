@@ -145,6 +145,25 @@ def test_direct_variant_agrees_with_production(stacker, small_stack):
         stacker.set_option("ecc_variant", 1)                                           # deleted in round 2
 
 
+@pytest.mark.parametrize("w,h,n,strength", [(1000, 700, 4, 1.0), (1920, 1080, 4, 4.0), (2000, 1200, 3, 12.0)])
+def test_lds_ring_path_is_bit_identical_to_the_gather_path(stacker, w, h, n, strength):
+    """The homography pass fetches the frame-0 rows of a column strip through a per-wave LDS ring (hand-issued LDS-DMA,
+    counted waits) wherever the strip's source footprint allows it, and gathers every tap from global memory elsewhere
+    (strip ends, frame borders, strong rotation: the third case has strips of both kinds). Both read the same taps and run
+    the same arithmetic: warps, iteration counts and the stacked image must not differ in a single bit."""
+    frames, _ = synth.make_stack(n, w, h, strength=strength)
+    dev = frames.cuda()
+    ring, s_ring = stacker.ecc_match(dev, PARAMS, return_stats=True)
+    stacker.set_option("ecc_ring", 0)
+    try:
+        gather, s_gather = stacker.ecc_match(dev, PARAMS, return_stats=True)
+    finally:
+        stacker.set_option("ecc_ring", 1)
+    assert [s["iterations"] for s in s_ring] == [s["iterations"] for s in s_gather]
+    assert all(np.array_equal(a["warp"], b["warp"]) for a, b in zip(s_ring, s_gather))
+    assert np.array_equal(ring.cpu().numpy(), gather.cpu().numpy())
+
+
 def test_slot_count_does_not_change_results(stacker, small_stack):
     frames, _ = small_stack
     base, s0 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
