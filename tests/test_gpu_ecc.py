@@ -120,7 +120,7 @@ def test_ecc_match_device_resident_equals_host_fed(stacker, small_stack):
 
 
 def test_direct_variant_agrees_with_production(stacker, small_stack):
-    # same per-pixel arithmetic, different accumulation structure (66 per-lane sums vs row-factorised moments): an
+    # same per-pixel arithmetic, different accumulation structure (66 per-lane sums vs per-strip Y-moments): an
     # independent cross-check of the production kernel; only the f32 summation order differs
     frames, _ = small_stack
     base, s0 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
