@@ -223,14 +223,14 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             const f32x2 vl = pk_fma(bc2(ay), g1a - g0a, g0a), vr = pk_fma(bc2(ay), g1b - g0b, g0b);
             bl.gw = pk_fma(bc2(ax), vr - vl, vl);                   // (gxw, gyw)
         };
-        auto accumulate = [&](auto fast_tag, const H8cRow& co, const H8cBlend& bl, int y) {
+        auto accumulate = [&](auto fast_tag, auto gather_tag, const H8cRow& co, const H8cBlend& bl, int y) {
             constexpr bool FAST = decltype(fast_tag)::value;
             if constexpr (!FAST) { if (!active) return; }
             // (Y, Y^2) as a real register pair: a broadcast half-pair would leave its other half to the register
             // allocator, and when that is the target of a load in flight the compiler waits for the load
             const float fy = (float)y;
             f32x2 fyv = {fy, fy * fy};
-            asm("" : "+v"(fyv));
+            if constexpr (decltype(gather_tag)::value) asm("" : "+v"(fyv));
             const f32x2 FY = bc2(fyv.x), FYY = bc2(fyv.y);
             const f32x2 sxy = co.s;
             const float rw = co.rw, Iw = bl.Iw;
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             issue(y0, ca, ta, ua);
             for (int y = y0; y < y1; y += 2) {
                 issue(y + 1, cb, tb, ub);
-                blend(ca, ta, ua, bl); accumulate(fast_tag, ca, bl, y);
+                blend(ca, ta, ua, bl); accumulate(fast_tag, std::true_type{}, ca, bl, y);
                 issue(y + 2, ca, ta, ua);
-                if (y + 1 < y1) { blend(cb, tb, ub, bl); accumulate(fast_tag, cb, bl, y + 1); }
+                if (y + 1 < y1) { blend(cb, tb, ub, bl); accumulate(fast_tag, std::true_type{}, cb, bl, y + 1); }
             }
             if constexpr (FAST) s_mf += (float)(y1 - y0);
         };
@@ -364,8 +364,11 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             };
             // wait until only the `keep` newest transfers are in flight (they complete in order); keep is 1 + 2 * rows (+ 2)
             auto wait_keep = [&](int keep) {
-                if (keep & 4) { if (keep & 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-                else { if (keep & 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+                const int k = __builtin_amdgcn_readfirstlane(keep);
+                if (k == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else if (k == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if (k == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             };
             // coordinates of row y, its taps and template sample out of the ring; returns the lanes' extreme source rows
             auto fetch = [&](int y, H8cRow& co, H8cTaps& top, H8cTaps& bot, int& ilo, int& ihi) {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 if (loaded < ihi + 4) dma_row();
                 dma_templ();
                 prev_issued = issued;
-                blend(cur, tcur, ucur, bl); accumulate(std::true_type{}, cur, bl, y);
+                blend(cur, tcur, ucur, bl); accumulate(std::true_type{}, std::false_type{}, cur, bl, y);
             };
             for (int y = y0; y < y1; y += 2) {
                 step(ca, ta, ua, cb, tb, ub, y);
