@@ -178,6 +178,9 @@ void        stk_host_free(void* p);
  *   "profile_stride"     with profile = 2: bracket every n-th ECC launch only
  *   "prep_stream"        1 (default): ECC templates of a run of frames by the streaming grey + blur kernel, one launch per
  *                        run; 0: the LDS-tiled kernel, frame by frame. Same bits either way
+ *   "prep_overlap"       1 (default): on a device-resident stack of more than 2 x "ecc_slots" frames the ECC templates are
+ *                        prepared on a second stream while the first frames already iterate; 0: all templates first.
+ *                        Same bits either way (stk_timing.prep_ms then covers the reference frame only)
  *   "upload_batch"       host-fed stacks: frames per host -> HBM batch (default 8); a batch is the unit the ECC queue
  *                        and the batched ORB wait for */
 stk_status  stk_set_option(stk_ctx* ctx, const char* name, int64_t value);

@@ -46,6 +46,7 @@ struct stk_ctx {
     hipEvent_t gate_ev = nullptr, gate_ev2 = nullptr;
     const FrameGate* frame_gate = nullptr;   // set by the path-based entry points for the duration of one call
     int opt_warp_tune = 0;
+    int opt_prep_overlap = 1;             // ecc_match on a device-resident stack: templates prepared on the prep stream while the first frames iterate
     int opt_prep_stream = 1;              // 1: templates of a run of frames by the streaming grey+blur kernel in one launch; 0: tiled kernel, frame by frame
     int opt_upload_batch = 8;             // frames per host -> HBM batch
     std::string err;

@@ -63,8 +63,20 @@ __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motio
             if (lane == 0 && k < NS && frame >= 0) a.sums[(size_t)slot * ECC_MAX_SUMS + k] = v;
         }
     }
-    if (frame < 0) {                                        // idle slot: no ticket is drawn; one thread looks for a newly prepared frame
-        if (g == 0 && tid == 0) {
+    if (frame < 0) {
+        // Idle slot: look for a newly prepared frame — but only once all SOLVE_G workgroups of this launch have read
+        // `frame`, i.e. from the one that draws the last ticket. (Taking it from workgroup 0 right away let later-starting
+        // workgroups of the same launch see the slot as active: they published sums of stale partials and drew tickets,
+        // the count carried into the next launch and stage 2 ran before all of that launch's sums were in — a frame
+        // that entered an idle slot could come out one ulp or one iteration off, run to run.)
+        __shared__ int last_idle;
+        if (tid == 0) {
+            const int t = atomicAdd(&a.tickets[slot], 1);
+            last_idle = (t == SOLVE_G - 1);
+            if (last_idle) a.tickets[slot] = 0;
+        }
+        __syncthreads();
+        if (last_idle && tid == 0) {
             EccSlot* sl = a.slots + slot;
             slot_take_next(sl, queue, init_warps);
             if (sl->frame >= 0) sl->last_rho = 0;

@@ -161,6 +161,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
     else if (n == "warp_tune") ctx->opt_warp_tune = (int)value;
     else if (n == "prep_stream") ctx->opt_prep_stream = value != 0;
+    else if (n == "prep_overlap") ctx->opt_prep_overlap = value != 0;
     else if (n == "upload_batch") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "upload_batch out of range"); ctx->opt_upload_batch = (int)value; }
     else if (n == "ecc_blocks") { if (value != 0 && (value < 8 || value > 65536)) return fail(ctx, STK_INVALID_PARAMS, "ecc_blocks out of range"); ctx->opt_ecc_blocks = (int)value; }
     else return fail(ctx, STK_INVALID_PARAMS, "unknown option " + n);
@@ -491,7 +492,10 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     if (host_fed && (st = up.wait_batch(0, ctx->stream))) return bail(st);
     if ((st = prepare_reference(ctx->stream))) return bail(st);
-    if (!host_fed && (st = prepare_templates(1, n - 1, ctx->stream))) return st;
+    // (with `overlap_prep` the templates are prepared while the first frames already iterate: prep_ms is then the
+    // reference's share only and the templates' time is inside align_ms)
+    const bool overlap_prep = !host_fed && !scaled && ctx->opt_prep_overlap && n - 1 > 2 * pl.n_slots;
+    if (!host_fed && !overlap_prep && (st = prepare_templates(1, n - 1, ctx->stream))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     const float* seeds_dev = nullptr;
     if (seeds && n > 1) {
@@ -526,6 +530,27 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         if (fin) return fin;
         ctx->timing.h2d_ms = h2d; ctx->timing.h2d_bytes = (int64_t)(fb * (size_t)n);
         HIP_TRY(hipStreamSynchronize(ctx->prep_stream));
+    } else if (overlap_prep) {
+        // device-resident stack: the templates are prepared on the prep stream, 16 frames at a time, each run raising the
+        // queue's `ready` mark — the HBM-bound preparation runs under the VALU-bound iteration of the frames before it
+        EccQueue* q = ctx->queue.as<EccQueue>();
+        bool enqueued_all = false;
+        const EccFeed feed = [&](bool, int* enqueued) -> stk_status {
+            if (!enqueued_all) {
+                for (int first = 1; first < n; first += 16) {
+                    const int cnt = std::min(16, n - first);
+                    const stk_status fs = prepare_templates(first, cnt, ctx->prep_stream);
+                    if (fs) return fs;
+                    HIP_TRY(launch_ecc_set_ready(q, first + cnt - 1, ctx->prep_stream));
+                }
+                enqueued_all = true;
+            }
+            *enqueued = n - 1;                                  // nothing further depends on the host
+            return STK_OK;
+        };
+        st = ecc_run(ctx, pl, crit, seeds_dev, res, &feed);
+        HIP_TRY(hipStreamSynchronize(ctx->prep_stream));
+        if (st) return st;
     } else if ((st = ecc_run(ctx, pl, crit, seeds_dev, res))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
 

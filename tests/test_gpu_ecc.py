@@ -164,6 +164,29 @@ def test_lds_ring_path_is_bit_identical_to_the_gather_path(stacker, w, h, n, str
     assert np.array_equal(ring.cpu().numpy(), gather.cpu().numpy())
 
 
+def test_frames_entering_idle_slots_do_not_change_results(stacker):
+    """With the templates prepared on a second stream while the first frames already iterate (device-resident stacks of
+    more than 2 x ecc_slots frames) and with host-fed stacks, frames enter slots that have been idle for some launches.
+    That path once let a slot's ticket count drift by a launch (the idle slot's frame was taken while other workgroups
+    of the same solve launch had not read the slot yet), so a frame came out an ulp or an iteration off, run to run.
+    Every run must give the bits of the all-templates-first run."""
+    frames, _ = synth.make_stack(90, 640, 480)
+    dev = frames.cuda()
+    stacker.set_option("prep_overlap", 0)
+    try:
+        ref, s_ref = stacker.ecc_match(dev, PARAMS, return_stats=True)
+    finally:
+        stacker.set_option("prep_overlap", 1)
+    ref = ref.cpu().numpy()
+    pinned = frames.pin_memory()
+    for rep in range(6):
+        for src in (dev, pinned):
+            out, st = stacker.ecc_match(src, PARAMS, return_stats=True)
+            assert [s["iterations"] for s in st] == [s["iterations"] for s in s_ref], rep
+            assert all(np.array_equal(a["warp"], b["warp"]) for a, b in zip(st, s_ref)), rep
+            assert np.array_equal(out.cpu().numpy() if hasattr(out, "cpu") else out, ref), rep
+
+
 def test_slot_count_does_not_change_results(stacker, small_stack):
     frames, _ = small_stack
     base, s0 = stacker.ecc_match(list(frames), PARAMS, return_stats=True)
