@@ -265,11 +265,22 @@ def main() -> None:
             kernels.append({"kernel": "warp_accumulate_%s" % ("u16c3" if depth == 16 else "u8c3"),
                             "bytes": "frames x %d B/px source + 12 B/px accumulator write per launch" % (src_b // px),
                             "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(agg["warp_ms"] / args.steps, 3)})
-        if api == "ecc" and agg["prep_ms"] > 0:
-            pb = (src_b + 4 * px) * (frames.shape[0] - 1) * args.steps + (src_b + 24 * px) * args.steps
-            g = pb / agg["prep_ms"] / 1e6
-            kernels.append({"kernel": "grey_blur_u8c3 (+ ref_planes once)", "bytes": "3 B/px read + 4 B/px template write per frame",
-                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(agg["prep_ms"] / args.steps, 3)})
+        if api == "ecc" and world == 1:
+            # template preparation: in the timed steps it runs on the prep stream under the iteration of the first frames
+            # (its time is inside align_ms); its own stage timer needs a step with the overlap switched off, outside the
+            # timed region
+            st.set_option("prep_overlap", 0)
+            try:
+                run_shard(frames, accs[0])
+                prep_ms = st.timing()["prep_ms"]
+            finally:
+                st.set_option("prep_overlap", 1)
+            pb = (src_b + 4 * px) * (frames.shape[0] - 1) + (src_b + 24 * px)
+            g = pb / prep_ms / 1e6
+            kernels.append({"kernel": "grey_blur_stream (+ ref_planes once)", "bytes": "3 B/px read + 4 B/px template write per frame",
+                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(prep_ms, 3),
+                            "note": "one extra step with prep_overlap = 0 (not in the timed region); in the timed steps this runs "
+                                    "under the ECC iteration of the first frames"})
         if agg["fast_ms"] > 0:
             # FAST-9/16 + NMS + Harris short list over the 8 pyramid levels: reads each level's u8 pixels once
             g = agg["fast_pixels"] / agg["fast_ms"] / 1e6

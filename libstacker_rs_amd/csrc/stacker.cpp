@@ -207,13 +207,14 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     pl.ref_plane_floats = (size_t)pl.ref_stride * (h + 2 * REF_PAD);
     const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
     pl.nsums = ecc_nsums(P);
-    // Frames in flight per launch ("slots"): up to 32. Every (iterate, solve) launch pair costs ~20 us of solve latency
+    // Frames in flight per launch ("slots"): up to 48 (32 until the column-walking pass: 48 is another 2 % at 256 4K frames,
+    // 64 no better). Every (iterate, solve) launch pair costs ~20 us of solve latency
     // and launch gaps whatever it carries, so the more frames share it the better: 4 -> 32 slots is +13 % at 256 4K frames
     // and +12 % at 32 (all moving frames of a 32-frame shard then iterate in lockstep, no queue refill at all).
     // Workgroups per frame: a FIXED 288 (the 1152 per 4 frames tuned in round 1), as many as the frame has 4-row groups if
     // fewer. Fixed means that a frame's f32 summation partition depends on nothing but the frame size: its warp is
     // bit-identical however the stack is sharded over GPUs and however many frames happen to share the launch.
-    int slots = ctx->opt_ecc_slots > 0 ? ctx->opt_ecc_slots : 32;
+    int slots = ctx->opt_ecc_slots > 0 ? ctx->opt_ecc_slots : 48;
     pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
     const int units = (h + 3) / 4;                           // work units of one frame: 4-row groups (one row per wave per sweep)
     int nb = ctx->opt_ecc_blocks > 0 ? ctx->opt_ecc_blocks / pl.n_slots : 288;
