@@ -163,7 +163,8 @@ stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
 stk_status  stk_host_alloc(size_t bytes, void** out);
 void        stk_host_free(void* p);
 /* Tuning knobs. None changes a frame's warp or the stacked image except where noted:
- *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto: up to 48); changes no result
+ *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto: up to 48, 64 for frames up to 1080p, the stack divided
+ *                        evenly over the rounds); changes no result
  *   "ecc_blocks"         workgroups per ECC launch, all frames in flight together (0 = auto: 288 per frame); a non-zero
  *                        value changes the f32 summation partition, i.e. results at round-off level (within the stated
  *                        ECC tolerance)
@@ -178,7 +179,7 @@ void        stk_host_free(void* p);
  *   "profile_stride"     with profile = 2: bracket every n-th ECC launch only
  *   "prep_stream"        1 (default): ECC templates of a run of frames by the streaming grey + blur kernel, one launch per
  *                        run; 0: the LDS-tiled kernel, frame by frame. Same bits either way
- *   "prep_overlap"       1 (default): on a device-resident stack of more than 2 x "ecc_slots" (96) frames the ECC templates are
+ *   "prep_overlap"       1 (default): on a device-resident stack of more than 2 x "ecc_slots" frames the ECC templates are
  *                        prepared on a second stream while the first frames already iterate; 0: all templates first.
  *                        Same bits either way (stk_timing.prep_ms then covers the reference frame only)
  *   "upload_batch"       host-fed stacks: frames per host -> HBM batch (default 8); a batch is the unit the ECC queue

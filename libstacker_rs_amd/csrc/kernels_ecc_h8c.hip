@@ -103,8 +103,6 @@ constexpr int LG = LW * 4;                    // offset of the (gx, gy) pairs in
 constexpr int LK = 8;                         // rows in the ring (a power of two); slot LK duplicates slot 0's successor role
 constexpr int LT = 4;                         // template rows in flight
 constexpr int LWAVE = (LK + 1) * LROW + LT * 256;
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
 struct H8cBlend {              // the bilinear samples of a pixel: I, (gx, gy)
     float Iw;
@@ -308,10 +306,9 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
         // 4.1). Here every frame-0 row segment the strip needs is fetched ONCE, as aligned 16-byte pieces, by LDS-DMA
         // (global_load_lds_dwordx4: no registers held while in flight) into a ring of LK rows private to the wave — no
         // barrier anywhere — and the taps are ds_read2 with per-lane addresses; the template sample comes the same way
-        // through a four-row ring. ~20 tag look-ups per row instead of 81.
-        // Pipeline per template row y: wait for the DMA issued one step ago (the template's two steps ago) -> coordinates
-        // and tap reads of row y+1 -> DMA of the frame-0 rows row y+2 will need and of template row y+3 -> arithmetic
-        // of row y.
+        // through a four-row ring. 30 tag look-ups per row instead of 81.
+        // Pipeline per template row y: wait until only the previous step's transfers are in flight -> coordinates and tap
+        // reads of row y+1 -> DMA of the frame-0 rows row y+3 will read and of template row y+3 -> arithmetic of row y.
         auto run_ring = [&]() {
             const float* const gI = a.ref.I + xb;
             const float* const gG = a.ref.gxy + 2 * (ptrdiff_t)xb;

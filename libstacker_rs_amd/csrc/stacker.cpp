@@ -207,14 +207,21 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     pl.ref_plane_floats = (size_t)pl.ref_stride * (h + 2 * REF_PAD);
     const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
     pl.nsums = ecc_nsums(P);
-    // Frames in flight per launch ("slots"): up to 48 (32 until the column-walking pass: 48 is another 2 % at 256 4K frames,
-    // 64 no better). Every (iterate, solve) launch pair costs ~20 us of solve latency
-    // and launch gaps whatever it carries, so the more frames share it the better: 4 -> 32 slots is +13 % at 256 4K frames
-    // and +12 % at 32 (all moving frames of a 32-frame shard then iterate in lockstep, no queue refill at all).
+    // Frames in flight per launch ("slots"). Every (iterate, solve) launch pair costs ~25 us of solve latency and launch
+    // gaps whatever it carries, so the more frames share it the better — up to a point: past ~48 4K frames the launches get
+    // less efficient per frame than the saved pairs are worth. And the stack should go through the slots in equal rounds:
+    // 63 frames in 48 slots leave a second round of 15. So: at most 48 slots (64 up to 1080p), and the frames divided evenly
+    // over the rounds that takes. Measured: 255 x 4K frames 32 slots 59.0 ms, 43 slots 57.6, 48 58.5, 64 58.3; 63 x 1080p
+    // 32 slots 3.91 ms, 48 4.30, 63 3.76.
     // Workgroups per frame: a FIXED 288 (the 1152 per 4 frames tuned in round 1), as many as the frame has 4-row groups if
     // fewer. Fixed means that a frame's f32 summation partition depends on nothing but the frame size: its warp is
     // bit-identical however the stack is sharded over GPUs and however many frames happen to share the launch.
-    int slots = ctx->opt_ecc_slots > 0 ? ctx->opt_ecc_slots : 48;
+    int slots = ctx->opt_ecc_slots;
+    if (slots <= 0) {
+        const int cap = (size_t)w * h <= (size_t)1920 * 1088 ? 64 : 48;
+        const int rounds = (std::max(n_templates, 1) + cap - 1) / cap;
+        slots = (std::max(n_templates, 1) + rounds - 1) / rounds;
+    }
     pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
     const int units = (h + 3) / 4;                           // work units of one frame: 4-row groups (one row per wave per sweep)
     int nb = ctx->opt_ecc_blocks > 0 ? ctx->opt_ecc_blocks / pl.n_slots : 288;
