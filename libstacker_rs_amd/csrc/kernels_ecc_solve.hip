@@ -111,9 +111,11 @@ hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, 
 
 __global__ void ecc_init_kernel(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
                                 const float* init_warps, int ready0) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one workgroup: the per-frame results by all threads, the queue and the slots (in slot order: slot s starts with
+    // frame s) by thread 0 (a single thread doing everything took 60 us at 31 frames)
+    for (int f = threadIdx.x; f < n_frames; f += blockDim.x) { results[f].status = 3; results[f].iters = 0; results[f].rho = -1; }
+    if (threadIdx.x != 0) return;
     queue->next_frame = 0; queue->n_frames = n_frames; queue->frames_done = 0; queue->ready = ready0 < 0 ? n_frames : ready0;
-    for (int f = 0; f < n_frames; f++) { results[f].status = 3; results[f].iters = 0; results[f].rho = -1; }
     for (int s = 0; s < n_slots; s++) {
         tickets[s] = 0;
         slots[s].last_rho = 0;
@@ -123,7 +125,7 @@ __global__ void ecc_init_kernel(EccSlot* slots, int n_slots, int* tickets, EccQu
 
 hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
                            const float* init_warps, hipStream_t s, int ready0) {
-    ecc_init_kernel<<<1, 64, 0, s>>>(slots, n_slots, tickets, queue, n_frames, results, init_warps, ready0);
+    ecc_init_kernel<<<1, 256, 0, s>>>(slots, n_slots, tickets, queue, n_frames, results, init_warps, ready0);
     return hipGetLastError();
 }
 
