@@ -164,6 +164,43 @@ def test_lds_ring_path_is_bit_identical_to_the_gather_path(stacker, w, h, n, str
     assert np.array_equal(ring.cpu().numpy(), gather.cpu().numpy())
 
 
+def test_lds_ring_against_gather_on_random_start_warps(stacker):
+    """The ring route decides per column strip whether its source footprint fits (window of 76 columns, lanes at most 2.5
+    rows apart, source row rising by 0.6 .. 1.4 per template row, corners with w >= 1/4) and falls back to the gather loop
+    otherwise. Random start homographies — rotations up to 8 degrees, scale 0.8 .. 1.25, perspective, shifts — put strips on
+    every side of those limits; two fixed iterations from each start must give the same bits by both routes."""
+    rng = np.random.default_rng(7)
+    frames, _ = synth.make_stack(2, 1280, 960)
+    g0, g1 = oracle.grey(frames.numpy()[0]), oracle.grey(frames.numpy()[1])
+    p2 = EccMatchParameters(MotionType.Homography, 2, None, 5)
+    w, h = 1280, 960
+    n_checked = 0
+    for k in range(24):
+        th = np.radians(rng.uniform(-8, 8)) * (k % 3 != 0)
+        sc = rng.uniform(0.8, 1.25) if k % 2 else rng.uniform(0.97, 1.03)
+        C = np.array([[1, 0, w / 2], [0, 1, h / 2], [0, 0, 1.0]])
+        R = np.array([[np.cos(th) * sc, -np.sin(th) * sc, rng.uniform(-30, 30)], [np.sin(th) * sc, np.cos(th) * sc, rng.uniform(-30, 30)],
+                      [rng.uniform(-2e-5, 2e-5), rng.uniform(-2e-5, 2e-5), 1.0]])
+        W0 = C @ R @ np.linalg.inv(C)
+        W0 = (W0 / W0[2, 2]).astype(np.float32)
+        W0[2, 2] = 1.0
+        outs = []
+        for ring in (1, 0):
+            stacker.set_option("ecc_ring", ring)
+            try:
+                outs.append(stacker.find_transform_ecc(g0, g1, W0.copy(), p2))
+            except OpenCvError as e:                       # a start this far off may fail like OpenCV's does: then by both routes
+                outs.append(str(e))
+            finally:
+                stacker.set_option("ecc_ring", 1)
+        if isinstance(outs[0], str) or isinstance(outs[1], str):
+            assert isinstance(outs[0], str) and isinstance(outs[1], str), (k, outs)
+            continue
+        n_checked += 1
+        assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], k
+    assert n_checked >= 12
+
+
 def test_frames_entering_idle_slots_do_not_change_results(stacker):
     """With the templates prepared on a second stream while the first frames already iterate (device-resident stacks of
     more than 2 x ecc_slots frames) and with host-fed stacks, frames enter slots that have been idle for some launches.
