@@ -243,9 +243,9 @@ def main() -> None:
             launches = agg["ecc_iter_launches"]                     # every launch of the timed region (incl. drained no-ops)
             avg_ms = agg["ecc_iter_ms"] / agg["ecc_iter_timed"]     # event-timed sample of them
             achieved = (alg_bytes_total / launches) / (avg_ms * 1e-3) / 1e9
-            traffic, tsrc = pmc_traffic(args, world, "stk::ecc_iter_h8c_kernel")
+            traffic, tsrc = pmc_traffic(args, world, "stk::ecc_iter_col_kernel<3>")
             res["roofline"] = {
-                "kernel": "ecc_iter_h8c_kernel (ECC iteration pass, homography)",
+                "kernel": "ecc_iter_col_kernel<homography> (ECC iteration pass)",
                 # `bound` names the roofline the figure is priced against (the contract's vocabulary: hbm | mfma); what
                 # actually limits the kernel is VALU issue (~92 instructions per pixel, ablation in DESIGN.md 4.7)
                 "bound": "hbm", "limiter": "valu-issue",
@@ -255,7 +255,7 @@ def main() -> None:
                 "timing": f"HIP event pair around every {stride}{'rd' if stride == 3 else 'th'} launch of the timed region, engine stream "
                           "(rocprofv3 --kernel-trace mean over ALL launches of the same command: profiles/)",
                 "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
-            kernels.append({"kernel": "ecc_iter_h8c_kernel", "bytes": "16 B/px/frame-iteration", "GBps": round(achieved, 1),
+            kernels.append({"kernel": "ecc_iter_col_kernel<homography>", "bytes": "16 B/px/frame-iteration", "GBps": round(achieved, 1),
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(avg_ms * launches / args.steps, 3)})
         if agg["warp_ms"] > 0:
             # fused fold: every frame's source read once + the accumulator written once per launch (no read: the launch
@@ -368,9 +368,9 @@ def pmc_traffic(args, world, kernel_prefix):
             allk = json.load(open(path))
             pm = next(v for k, v in allk.items() if k.startswith(kernel_prefix))
             want = allk.get("_kernel_source_sha256")
-            have = hashlib.sha256(open(os.path.join(ROOT, "libstacker_rs_amd", "csrc", "kernels_ecc_h8c.hip"), "rb").read()).hexdigest()
+            have = hashlib.sha256(open(os.path.join(ROOT, "libstacker_rs_amd", "csrc", "kernels_ecc_col.hip"), "rb").read()).hexdigest()
             if want is not None and want != have:
-                return None, f"profiles/{rnd}/pmc_summary.json is from an older kernels_ecc_h8c.hip: ignored"
+                return None, f"profiles/{rnd}/pmc_summary.json is from an older kernels_ecc_col.hip: ignored"
             if want is None and rnd == "r01":
                 return None, "profiles/r01/pmc_summary.json predates this round's kernel: ignored"
             return round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1), \

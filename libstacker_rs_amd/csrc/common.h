@@ -132,7 +132,7 @@ hipError_t launch_grey_blur_batch(const void* const* ptrs_dev, const void* base,
 hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
                              int ref_stride, hipStream_t s);
 // variant: 3 = production kernels, 0 = direct cross-check version
-hipError_t launch_ecc_iter_h8c(const EccIterArgs& a, hipStream_t s);   // kernels_ecc_h8c.hip; a.units_q / units_r set
+hipError_t launch_ecc_iter_col(const EccIterArgs& a, int motion, hipStream_t s);   // kernels_ecc_col.hip; a.units_q / units_r set
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s);
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
                             EccFrameResult* results, hipStream_t s, const float* init_warps = nullptr);

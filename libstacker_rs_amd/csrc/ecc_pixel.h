@@ -1,5 +1,5 @@
 // ecc_pixel.h — what the ECC iteration kernels share: tap types, the exact INTER_NEAREST mask test, the per-slot
-// constants. Included by kernels_ecc.hip and kernels_ecc_h8c.hip.
+// constants. Included by kernels_ecc.hip and kernels_ecc_col.hip.
 #pragma once
 #include "common.h"
 

@@ -9,15 +9,13 @@
 //  algorithmic traffic is 16 B/px.
 //
 //  Variants of the pass (option `ecc_variant`; same sums, they differ in the f32 summation order only):
-//   * 3 (default). Homography: ecc_iter_h8c_kernel in kernels_ecc_h8c.hip — a wave walks DOWN a 64-pixel column strip,
-//     so X is a lane constant and Y a scalar; Y-moments per lane, one cross-lane fold per strip (see that file).
-//     Translation / euclidean / affine: ecc_iter_affine_kernel here — lane-adjacent pixels along a row, taps through one
-//     32-bit offset on scalar bases, two-stage software pipeline, plain accumulators.
-//   * 0: direct — one wave per template row, lanes stream aligned 16-byte template quads, 66 per-lane
-//     accumulators, every tap a global gather (the first version; kept as a cross-check).
+//   * 3 (default): ecc_iter_col_kernel<MOTION> in kernels_ecc_col.hip — a wave walks DOWN a 64-pixel column strip, so X
+//     is a lane constant and Y a scalar; frame-0 rows through a per-wave LDS ring; one cross-lane fold per strip.
+//   * 0: direct (this file) — one wave per template row, lanes stream aligned 16-byte template quads, one accumulator per
+//     sum and lane, every tap a global gather (the first version; kept as a cross-check).
 //  History of the homography pass (4-slot 4K launch, then 32-slot): direct 182 us -> row-walking factorised pass 98 us
 //  (round 1; VALU-issue-bound at ~97 instructions per pixel) -> 0.70 ms per 32-slot launch (round 2, fixed 288 blocks) ->
-//  column-walking pass 0.61 ms (~60 instructions per pixel; no longer bound by VALU issue).
+//  column-walking pass 0.61 ms -> with the LDS ring 0.58 ms.
 //
 //  Several frames ("slots") iterate concurrently in one launch. blockIdx is decoded so that the
 //  blocks working on the SAME image region for different slots share blockIdx % 8, i.e. one XCD and
@@ -190,106 +188,20 @@ __global__ __launch_bounds__(256) void ecc_iter_kernel(EccIterArgs a) {
     block_reduce_store<NS>(acc, a, slot, region);
 }
 
-// one pixel in flight between the two pipeline stages of the affine-family pass
-struct H8Px {
-    float sx, sy, rw, ax, ay, tval;
-    f32x2_a4 i0, i1;
-    f32x4_a8 g0, g1;
-    int x;
-};
-
-// ---------------------------------------------------------------------------------------------------
-// translation / euclidean / affine (variant 3 for these motions): the data movement of the row-factorised kernel
-// (lane-adjacent pixels, one 32-bit tap offset on scalar bases, (gx, gy) interleaved, two-stage software pipeline)
-// with the plain per-lane moment accumulators — these motions have 15 / 21 / 45 sums, so there is nothing to factorise.
-// Per-pixel arithmetic is accumulate_pixel's, i.e. identical to the direct variant up to the f32 summation order.
-// ---------------------------------------------------------------------------------------------------
-template <int MOTION>
-__global__ __launch_bounds__(256, 3) void ecc_iter_affine_kernel(EccIterArgs a) {
-    constexpr int P = MotionTraits<MOTION>::P;
-    constexpr int NS = P * (P + 1) / 2 + 3 * P + 6;
-    const int bid = (int)blockIdx.x;
-    const int xcd = bid & 7, q = bid >> 3;
-    const int slot = a.slot0 + q % a.n_slots;
-    const int region = (q / a.n_slots) * 8 + xcd;
-    const EccSlot* sl = a.slots + slot;
-    const int frame = sl->frame;
-    if (frame < 0) return;
-    SlotConst c;
-    load_slot_const(sl, a, c);
-    const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float acc[NS];
-#pragma unroll
-    for (int k = 0; k < NS; k++) acc[k] = 0.f;
-    const int rs = a.ref.stride;
-    const int corner = REF_PAD * rs + REF_PAD;
-    const char* __restrict__ Ib = reinterpret_cast<const char*>(a.ref.I - corner);
-    const char* __restrict__ Gb = reinterpret_cast<const char*>(a.ref.gxy - 2 * (size_t)corner);
-    const char* __restrict__ Ib1 = Ib + (size_t)rs * 4;
-    const char* __restrict__ Gb1 = Gb + (size_t)rs * 8;
-    const int nchunk = (a.tw + 63) >> 6;
-    for (int y = region * 4 + wave; y < a.th; y += a.nb * 4) {
-        const float fy = (float)y;
-        const float rowX = __builtin_fmaf(c.m1, fy, c.m2), rowY = __builtin_fmaf(c.m4, fy, c.m5);
-        const float* trow = T + (size_t)y * a.templ_row_stride;
-        auto stage_a = [&](int x, H8Px& p) {
-            const int xc = min(x, a.tw - 1);                  // past the row end: a harmless repeat, skipped in stage B
-            p.x = x;
-            p.tval = trow[xc];
-            const float fx = (float)xc;
-            const float sx = __builtin_fmaf(c.m0, fx, rowX), sy = __builtin_fmaf(c.m3, fx, rowY);
-            p.sx = sx; p.sy = sy; p.rw = 1.0f;
-            const float flx = __builtin_floorf(sx), fly = __builtin_floorf(sy);
-            p.ax = sx - flx; p.ay = sy - fly;
-            const int ix = (int)__builtin_amdgcn_fmed3f(flx, -2.0f, c.fiw);
-            const int iy = (int)__builtin_amdgcn_fmed3f(fly, -2.0f, c.fih);
-            const unsigned bo = (unsigned)(__mul24(iy, rs) + ix + corner) << 2;
-            p.i0 = *(const f32x2_a4*)(Ib + bo); p.i1 = *(const f32x2_a4*)(Ib1 + bo);
-            p.g0 = *(const f32x4_a8*)(Gb + 2u * bo); p.g1 = *(const f32x4_a8*)(Gb1 + 2u * bo);
-        };
-        auto stage_b = [&](const H8Px& p) {
-            if (p.x >= a.tw) return;
-            const float Iw = bilerp4(p.i0.x, p.i0.y, p.i1.x, p.i1.y, p.ax, p.ay);
-            const float gxw = bilerp4(p.g0.x, p.g0.z, p.g1.x, p.g1.z, p.ax, p.ay);
-            const float gyw = bilerp4(p.g0.y, p.g0.w, p.g1.y, p.g1.w, p.ax, p.ay);
-            accumulate_pixel<MOTION, NS>(c, sl->warp, p.x, y, (float)p.x, fy, p.sx, p.sy, 1.0f, 0.0f, 0.0f, Iw, gxw, gyw, p.tval, acc);
-        };
-        H8Px p0, p1;
-        stage_a(lane, p0);
-        for (int k = 0; k < nchunk; k += 2) {
-            stage_a((k + 1) * 64 + lane, p1);
-            stage_b(p0);
-            stage_a((k + 2) * 64 + lane, p0);
-            stage_b(p1);
-        }
-    }
-    block_reduce_store<NS>(acc, a, slot, region);
-}
-
-// variant 3: the production kernels (column-walking homography pass, kernels_ecc_h8c.hip / pipelined affine family);
-// variant 0: the first, direct version (66 per-lane accumulators) — kept as an independent cross-check in the tests and
-// for a caller-supplied initial homography whose m22 is not 1. (Three more were measured and deleted: LDS-tiled with
-// LDS-DMA and row-sharing slots in round 1, the row-walking factorised pass in round 2 when the column-walking one
-// overtook it.)
+// variant 3: the production kernel (column-walking pass, kernels_ecc_col.hip, every motion model); variant 0: the first,
+// direct version (one accumulator per sum and lane, every tap a global gather) — kept as an independent cross-check in the
+// tests and for a caller-supplied initial homography whose m22 is not 1. (Measured and deleted: LDS-tiled with LDS-DMA and
+// row-sharing slots in round 1; the row-walking factorised homography pass and the row-walking affine-family pass in round
+// 2, when the column-walking one overtook them.)
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s) {
     const int grid = a.nb * a.n_slots;
     if (grid <= 0) return hipSuccess;
-    if (variant == 3 && motion == STK_MOTION_HOMOGRAPHY) {
+    if (variant == 3) {
         EccIterArgs b = a;
         const long long units = (long long)((a.tw + 63) >> 6) * a.th;
         if (units > 0x3fffffffLL) return hipErrorInvalidValue;
         b.units_q = (int)(units / (a.nb * 4)); b.units_r = (int)(units % (a.nb * 4));
-        return launch_ecc_iter_h8c(b, s);
-    }
-    if (variant == 3) {
-        switch (motion) {
-            case STK_MOTION_AFFINE: ecc_iter_affine_kernel<STK_MOTION_AFFINE><<<grid, 256, 0, s>>>(a); break;
-            case STK_MOTION_EUCLIDEAN: ecc_iter_affine_kernel<STK_MOTION_EUCLIDEAN><<<grid, 256, 0, s>>>(a); break;
-            case STK_MOTION_TRANSLATION: ecc_iter_affine_kernel<STK_MOTION_TRANSLATION><<<grid, 256, 0, s>>>(a); break;
-            default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
+        return launch_ecc_iter_col(b, motion, s);
     }
     switch (motion) {
         case STK_MOTION_HOMOGRAPHY: ecc_iter_kernel<STK_MOTION_HOMOGRAPHY><<<grid, 256, 0, s>>>(a); break;

@@ -1,5 +1,5 @@
-// kernels_ecc_h8c.hip — the column-walking iteration pass of findTransformECC for homographies (lib.rs:769-777;
-// algorithm SURVEY.md 8a-E*). Same 66 moment sums and the same partials layout as the kernels in kernels_ecc.hip.
+// kernels_ecc_col.hip — the column-walking iteration pass of findTransformECC (lib.rs:769-777; algorithm SURVEY.md
+// 8a-E*), every motion model. Same moment sums and the same partials layout as the direct kernels in kernels_ecc.hip.
 // Compiled with -fno-slp-vectorize (Makefile): every pair is written out as float2 here, and the vectoriser's own
 // pairings cost register shuffles.
 #include "ecc_pixel.h"
@@ -7,8 +7,8 @@
 
 namespace stk {
 
-#ifndef STK_H8_WG
-#define STK_H8_WG 4
+#ifndef STK_COL_WG
+#define STK_COL_WG 4
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -86,12 +86,12 @@ __device__ __forceinline__ void lane_transpose_sum(float (&v)[N], int lane) {
 }
 
 // one tap row of a pixel: I at (ix, ix + 1) and (gx, gy) at (ix, ix + 1)
-struct H8cTaps {
+struct ColTaps {
     f32x2_a4 i;
     f32x4_a8 g;
 };
 // a row in flight besides its taps: source coordinate, its fractional part, 1/w, the template sample
-struct H8cRow {
+struct ColRow {
     f32x2 s, frac;
     float rw, tval;
 };
@@ -104,14 +104,19 @@ constexpr int LK = 8;                         // rows in the ring (a power of tw
 constexpr int LT = 4;                         // template rows in flight
 constexpr int LWAVE = (LK + 1) * LROW + LT * 256;
 
-struct H8cBlend {              // the bilinear samples of a pixel: I, (gx, gy)
+struct ColBlend {              // the bilinear samples of a pixel: I, (gx, gy)
     float Iw;
     f32x2 gw;
 };
 
-__global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArgs a) {
-    constexpr int MOTION = STK_MOTION_HOMOGRAPHY;
-    constexpr int P = 8, NH = 36, NS = NH + 3 * P + 6;
+// MOTION: the homography runs the factorised accumulation described above; translation / euclidean / affine have 15 /
+// 21 / 45 sums, nothing to factorise, and keep one plain accumulator per sum (the Jacobian is formed per pixel from the
+// lane's constant X and the row's Y) — same strips, same ring, same fold. Their warps carry (0, 0, 1) in the last row, so
+// the projective coordinate code serves them unchanged (1/w is exactly 1).
+template <int MOTION>
+__global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterArgs a) {
+    constexpr bool HOMOGRAPHY = MOTION == STK_MOTION_HOMOGRAPHY;
+    constexpr int P = MotionTraits<MOTION>::P, NH = P * (P + 1) / 2, NS = NH + 3 * P + 6;
     const int bid = (int)blockIdx.x;
     const int xcd = bid & 7, q = bid >> 3;
     const int slot = a.slot0 + q % a.n_slots;
@@ -140,14 +145,20 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
     float m0tm, m1tm;                // t.m
     float s_mf, s_x;                 // sum m, sum um.v
     f32x2 s_uv, s_sq;                // (sum um, sum v), (sum um.u, sum v.v)
+    float accp[HOMOGRAPHY ? 1 : NS];  // the other motions: one accumulator per sum, in the order of the partials
     auto clear = [&]() {
+        if constexpr (HOMOGRAPHY) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            hq[k][0] = hq[k][1] = hq[k][2] = bc2(0.f);
-            m0ab[k] = m1ab[k] = bc2(0.f);
+            for (int k = 0; k < 3; k++) {
+                hq[k][0] = hq[k][1] = hq[k][2] = bc2(0.f);
+                m0ab[k] = m1ab[k] = bc2(0.f);
+            }
+            m0t = m1t = s_uv = s_sq = bc2(0.f);
+            m0tm = m1tm = s_mf = s_x = 0.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; k++) accp[k] = 0.f;
         }
-        m0t = m1t = s_uv = s_sq = bc2(0.f);
-        m0tm = m1tm = s_mf = s_x = 0.f;
     };
     clear();
     double dacc0 = 0.0, dacc1 = 0.0;  // lane L: totals of sum number bitreverse6(L) and 64 + bitreverse6(L)
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             sxy = XY * bc2(rw);                           // hatX = -X'/den and hatY = -Y'/den are exactly -sx, -sy (den == w)
             fl = f32x2{__builtin_floorf(sxy.x), __builtin_floorf(sxy.y)};
         };
-        auto blend = [&](const H8cRow& co, const H8cTaps& top, const H8cTaps& bot, H8cBlend& bl) {
+        auto blend = [&](const ColRow& co, const ColTaps& top, const ColTaps& bot, ColBlend& bl) {
             const float ax = co.frac.x, ay = co.frac.y;
             // bilinear taps, the vertical blend first: the two taps of a row are adjacent in memory, so the
             // row pairs go through v_pk_* as loaded
@@ -221,9 +232,55 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             const f32x2 vl = pk_fma(bc2(ay), g1a - g0a, g0a), vr = pk_fma(bc2(ay), g1b - g0b, g0b);
             bl.gw = pk_fma(bc2(ax), vr - vl, vl);                   // (gxw, gyw)
         };
-        auto accumulate = [&](auto fast_tag, auto gather_tag, const H8cRow& co, const H8cBlend& bl, int y) {
+        auto accumulate = [&](auto fast_tag, auto gather_tag, const ColRow& co, const ColBlend& bl, int y) {
             constexpr bool FAST = decltype(fast_tag)::value;
             if constexpr (!FAST) { if (!active) return; }
+            if constexpr (!HOMOGRAPHY) {
+                const float fy = (float)y, sx = co.s.x, sy = co.s.y, Iw = bl.Iw, gxw = bl.gw.x, gyw = bl.gw.y;
+                bool inside = true;
+                if constexpr (!FAST) {
+                    inside = (sx > 0.0f) & (sx < c.mxw) & (sy > 0.0f) & (sy < c.mxh);
+                    if (!inside) {
+                        const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
+                        inside = (rx >= 0.0f) & (rx <= c.mxw) & (ry >= 0.0f) & (ry <= c.mxh);
+                        const bool edge = (__builtin_fabsf(sx + 0.5f) < 0.01f) | (__builtin_fabsf(sx - (c.mxw + 0.5f)) < 0.01f) |
+                                          (__builtin_fabsf(sy + 0.5f) < 0.01f) | (__builtin_fabsf(sy - (c.mxh + 0.5f)) < 0.01f);
+                        if (edge) inside = nearest_inside_exact<MOTION>(x, y, sl->warp, c.iw, c.ih);
+                    }
+                }
+                const float mf = inside ? 1.0f : 0.0f;
+                float J[P];
+                if constexpr (MOTION == STK_MOTION_AFFINE) {
+                    J[0] = gxw * fx; J[1] = gyw * fx; J[2] = gxw * fy; J[3] = gyw * fy; J[4] = gxw; J[5] = gyw;
+                } else if constexpr (MOTION == STK_MOTION_EUCLIDEAN) {
+                    const float ex = -(fx * c.m3) - (fy * c.m0);     // h0 = m00 (cos), h1 = m10 (sin)
+                    const float ey = (fx * c.m0) - (fy * c.m3);
+                    J[0] = gxw * ex + gyw * ey; J[1] = gxw; J[2] = gyw;
+                } else {
+                    J[0] = gxw; J[1] = gyw;
+                }
+                const float u = inside ? Iw - c.cI : Iw;
+                const float v = inside ? co.tval - c.cT : 0.0f;
+                int idx = 0;
+#pragma unroll
+                for (int k = 0; k < P; k++)
+#pragma unroll
+                    for (int l = k; l < P; l++) { accp[idx] = __builtin_fmaf(J[k], J[l], accp[idx]); idx++; }
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    accp[NH + k] = __builtin_fmaf(J[k], u, accp[NH + k]);
+                    accp[NH + P + k] = __builtin_fmaf(J[k], v, accp[NH + P + k]);
+                    accp[NH + 2 * P + k] = __builtin_fmaf(J[k], mf, accp[NH + 2 * P + k]);
+                }
+                const float um = u * mf;
+                accp[NH + 3 * P + 0] += mf;
+                accp[NH + 3 * P + 1] += um;
+                accp[NH + 3 * P + 2] = __builtin_fmaf(um, u, accp[NH + 3 * P + 2]);
+                accp[NH + 3 * P + 3] += v;
+                accp[NH + 3 * P + 4] = __builtin_fmaf(v, v, accp[NH + 3 * P + 4]);
+                accp[NH + 3 * P + 5] = __builtin_fmaf(um, v, accp[NH + 3 * P + 5]);
+                return;
+            }
             // (Y, Y^2) as a real register pair: a broadcast half-pair would leave its other half to the register
             // allocator, and when that is the target of a load in flight the compiler waits for the load
             const float fy = (float)y;
@@ -271,7 +328,7 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             constexpr bool FAST = decltype(fast_tag)::value;
             // Stage A of row y: coordinates, then the loads of the template sample and the 2 x 2 taps of the three planes
             // (five load instructions; what was tried instead is listed in DESIGN.md 4.1).
-            auto issue = [&](int y, H8cRow& co, H8cTaps& top, H8cTaps& bot) {
+            auto issue = [&](int y, ColRow& co, ColTaps& top, ColTaps& bot) {
                 const int yc = min(y, y1 - 1);                 // past the strip end: a harmless repeat, never used
                 asm volatile("" : "+v"(xoff));                 // keeps (row base) + (lane offset) in the saddr + voffset form
                 co.tval = *(const float*)((const char*)(T + (size_t)yc * a.templ_row_stride) + xoff);
@@ -288,9 +345,9 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 top.g = *(const f32x4_a8*)(Gb + 2u * bo); bot.g = *(const f32x4_a8*)(Gb1 + 2u * bo);
             };
             // Two rows in flight: the loads of row y+1 are issued before the arithmetic of row y.
-            H8cTaps ta, tb, ua, ub;
-            H8cRow ca, cb;
-            H8cBlend bl;
+            ColTaps ta, tb, ua, ub;
+            ColRow ca, cb;
+            ColBlend bl;
             issue(y0, ca, ta, ua);
             for (int y = y0; y < y1; y += 2) {
                 issue(y + 1, cb, tb, ub);
@@ -298,7 +355,7 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 issue(y + 2, ca, ta, ua);
                 if (y + 1 < y1) { blend(cb, tb, ub, bl); accumulate(fast_tag, std::true_type{}, cb, bl, y + 1); }
             }
-            if constexpr (FAST) s_mf += (float)(y1 - y0);
+            if constexpr (FAST && HOMOGRAPHY) s_mf += (float)(y1 - y0);
         };
         // ---- frame-0 rows through a per-wave LDS ring ----
         // The loop above is bound by the L1's tag pipeline: the 2 x 2 taps of a wave are overlapping 8- and 16-byte
@@ -368,7 +425,7 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             };
             // coordinates of row y, its taps and template sample out of the ring; returns the lanes' extreme source rows
-            auto fetch = [&](int y, H8cRow& co, H8cTaps& top, H8cTaps& bot, int& ilo, int& ihi) {
+            auto fetch = [&](int y, ColRow& co, ColTaps& top, ColTaps& bot, int& ilo, int& ihi) {
                 const int yc = min(y, y1 - 1);
                 f32x2 fl;
                 coords((float)yc, co.s, co.rw, fl);
@@ -383,9 +440,9 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 top.g.lo = pg[0]; top.g.hi = pg[1]; bot.g.lo = pg[LROW / 8]; bot.g.hi = pg[LROW / 8 + 1];
                 co.tval = ((const float*)(ring + (LK + 1) * LROW + (yc & (LT - 1)) * 256))[lane];
             };
-            H8cTaps ta, ua, tb, ub;
-            H8cRow ca, cb;
-            H8cBlend bl;
+            ColTaps ta, ua, tb, ub;
+            ColRow ca, cb;
+            ColBlend bl;
             int ilo, ihi;
             {   // fill: the rows of the first template row plus the lookahead, three template rows
                 f32x2 s0, fl0; float rw0;
@@ -408,7 +465,7 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
             // 1.4 per template row) and template row y+3. Nothing a later fetch needs is overwritten: the rows in flight
             // reach back to ihi(y+1) - 4 at most, the lanes of a row differ by at most 3.
             int prev_issued = 1;                                 // (nothing is in flight before the first step)
-            auto step = [&](H8cRow& cur, H8cTaps& tcur, H8cTaps& ucur, H8cRow& nxt, H8cTaps& tnxt, H8cTaps& unxt, int y) {
+            auto step = [&](ColRow& cur, ColTaps& tcur, ColTaps& ucur, ColRow& nxt, ColTaps& tnxt, ColTaps& unxt, int y) {
                 wait_keep(prev_issued);
                 fetch(y + 1, nxt, tnxt, unxt, ilo, ihi);
                 issued = 0;
@@ -423,13 +480,17 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 if (y + 1 < y1) step(cb, tb, ub, ca, ta, ua, y + 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in the ring after the strip (it is reused)
-            s_mf += (float)(y1 - y0);
+            if constexpr (HOMOGRAPHY) s_mf += (float)(y1 - y0);
         };
         if (ringable) run_ring(); else if (fast) run(std::true_type{}); else run(std::false_type{});
 
         // flush the strip: apply the powers of X, sum over the 64 lanes, add to the f64 totals
         {
             float v[NS];
+            if constexpr (!HOMOGRAPHY) {
+#pragma unroll
+                for (int k = 0; k < NS; k++) v[k] = accp[k];
+            } else {
             const float fxx = fx * fx;
             int idx = 0;
 #pragma unroll
@@ -456,15 +517,17 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
                 }
             v[NH + 3 * P + 0] = s_mf; v[NH + 3 * P + 1] = s_uv.x; v[NH + 3 * P + 2] = s_sq.x;
             v[NH + 3 * P + 3] = s_uv.y; v[NH + 3 * P + 4] = s_sq.y; v[NH + 3 * P + 5] = s_x;
+            }
             lane_transpose_sum<NS>(v, lane);
-            dacc0 += (double)v[0]; dacc1 += (double)v[1];
+            dacc0 += (double)v[0];
+            if constexpr (NS > 64) dacc1 += (double)v[1];
             clear();
         }
     }
 
     __shared__ double red[4][NS];
     const int k0 = (int)(__builtin_bitreverse32((unsigned)lane) >> 26);
-    red[wave][k0] = dacc0;
+    if (k0 < NS) red[wave][k0] = dacc0;
     if (k0 + 64 < NS) red[wave][k0 + 64] = dacc1;
     __syncthreads();
     if (threadIdx.x < NS) {
@@ -474,8 +537,15 @@ __global__ __launch_bounds__(256, STK_H8_WG) void ecc_iter_h8c_kernel(EccIterArg
     }
 }
 
-hipError_t launch_ecc_iter_h8c(const EccIterArgs& a, hipStream_t s) {
-    ecc_iter_h8c_kernel<<<a.nb * a.n_slots, 256, 0, s>>>(a);
+hipError_t launch_ecc_iter_col(const EccIterArgs& a, int motion, hipStream_t s) {
+    const int grid = a.nb * a.n_slots;
+    switch (motion) {
+        case STK_MOTION_HOMOGRAPHY: ecc_iter_col_kernel<STK_MOTION_HOMOGRAPHY><<<grid, 256, 0, s>>>(a); break;
+        case STK_MOTION_AFFINE: ecc_iter_col_kernel<STK_MOTION_AFFINE><<<grid, 256, 0, s>>>(a); break;
+        case STK_MOTION_EUCLIDEAN: ecc_iter_col_kernel<STK_MOTION_EUCLIDEAN><<<grid, 256, 0, s>>>(a); break;
+        case STK_MOTION_TRANSLATION: ecc_iter_col_kernel<STK_MOTION_TRANSLATION><<<grid, 256, 0, s>>>(a); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

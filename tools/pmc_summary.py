@@ -6,7 +6,7 @@ the guide says to double it for 16-B-per-lane streams and to calibrate other acc
 calibration rows are in the same run: `scale_kernel` (float4 stream, 4 B read per float), `grey_blur_u8c3_kernel`
 (aligned dword loads of a BGR byte stream: 3 B/px read, 4 B/px written) and `warp_accumulate_u8c3_kernel` (unaligned
 8-byte gathers: ~3 B/px/frame). `_calibration` lists raw FETCH_SIZE / known bytes for each.
-`_kernel_source_sha256` pins the summary to the kernels_ecc_h8c.hip it was measured with (bench.py ignores a stale one)."""
+`_kernel_source_sha256` pins the summary to the kernels_ecc_col.hip it was measured with (bench.py ignores a stale one)."""
 import collections
 import csv
 import glob
@@ -52,5 +52,5 @@ for k, v in res.items():
         v['parked_frac_of_wave_cycles'] = v.get('SQ_WAIT_ANY_per_dispatch', 0.0) / wc
         v['issue_stall_frac_of_wave_cycles'] = v.get('SQ_WAIT_INST_ANY_per_dispatch', 0.0) / wc
 out = dict(res)
-out['_kernel_source_sha256'] = hashlib.sha256(open(os.path.join(root, 'libstacker_rs_amd', 'csrc', 'kernels_ecc_h8c.hip'), 'rb').read()).hexdigest()
+out['_kernel_source_sha256'] = hashlib.sha256(open(os.path.join(root, 'libstacker_rs_amd', 'csrc', 'kernels_ecc_col.hip'), 'rb').read()).hexdigest()
 print(json.dumps(out, indent=1, sort_keys=True))
