@@ -103,6 +103,8 @@ constexpr int LG = LW * 4;                    // offset of the (gx, gy) pairs in
 constexpr int LK = 8;                         // rows in the ring (a power of two); slot LK duplicates slot 0's successor role
 constexpr int LT = 4;                         // template rows in flight
 constexpr int LWAVE = (LK + 1) * LROW + LT * 256;
+static_assert(4 * (4 * LWAVE + 4 * 66 * 8) <= 160 * 1024, "four workgroups (rings + the block reduction's 4 x 66 doubles) must fit a CU's 160 KB of LDS");
+static_assert(LROW / 4 + 1 < 256 && LROW / 8 + 1 < 256, "the lower tap row is addressed through ds_read2's 8-bit offset");
 
 struct ColBlend {              // the bilinear samples of a pixel: I, (gx, gy)
     float Iw;
