@@ -10,6 +10,9 @@ namespace stk {
 #ifndef STK_COL_WG
 #define STK_COL_WG 4
 #endif
+#ifndef STK_COL_LOOKAHEAD
+#define STK_COL_LOOKAHEAD 4      // frame-0 rows kept ahead of the row being fetched (a smaller value makes the run-time check fire: tested once)
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // The row-walking pass this one replaced ran ~97 VALU instructions per pixel (95 in the loop, the rest in row-end and
@@ -466,13 +469,21 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
             // so step y fetches what row y+3 will read: frame-0 rows up to ihi(y+1) + 4 (the source row rises by at most
             // 1.4 per template row) and template row y+3. Nothing a later fetch needs is overwritten: the rows in flight
             // reach back to ihi(y+1) - 4 at most, the lanes of a row differ by at most 3.
+            // The bounds that make this safe were derived from the strip's corners before the loop; they are also CHECKED, on
+            // scalars, row by row: what fetch() is about to read must have landed (`safe`) and must not have been
+            // overwritten by anything issued since. A violation poisons one of the strip's sums with a NaN — the solve step
+            // then fails the frame (status NaN) instead of a wrong warp going unnoticed.
             int prev_issued = 1;                                 // (nothing is in flight before the first step)
+            int safe = loaded, before_prev = loaded, violated = 0;
             auto step = [&](ColRow& cur, ColTaps& tcur, ColTaps& ucur, ColRow& nxt, ColTaps& tnxt, ColTaps& unxt, int y) {
                 wait_keep(prev_issued);
+                safe = before_prev;                               // everything issued before the previous step's transfers has landed
                 fetch(y + 1, nxt, tnxt, unxt, ilo, ihi);
+                violated |= (safe - (ihi + 1)) | (ilo + LK - 1 - loaded);   // a sign bit: read before it landed / after it was overwritten
+                before_prev = loaded;
                 issued = 0;
-                if (loaded < ihi + 4) dma_row();
-                if (loaded < ihi + 4) dma_row();
+                if (loaded < ihi + STK_COL_LOOKAHEAD) dma_row();
+                if (loaded < ihi + STK_COL_LOOKAHEAD) dma_row();
                 dma_templ();
                 prev_issued = issued;
                 blend(cur, tcur, ucur, bl); accumulate(std::true_type{}, std::false_type{}, cur, bl, y);
@@ -482,6 +493,7 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 if (y + 1 < y1) step(cb, tb, ub, ca, ta, ua, y + 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in the ring after the strip (it is reused)
+            if (violated < 0) { if constexpr (HOMOGRAPHY) s_x = __builtin_nanf(""); else accp[NS - 1] = __builtin_nanf(""); }
             if constexpr (HOMOGRAPHY) s_mf += (float)(y1 - y0);
         };
         if (ringable) run_ring(); else if (fast) run(std::true_type{}); else run(std::false_type{});
