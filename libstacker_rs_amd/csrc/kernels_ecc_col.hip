@@ -11,7 +11,7 @@ namespace stk {
 #define STK_COL_WG 4
 #endif
 #ifndef STK_COL_LOOKAHEAD
-#define STK_COL_LOOKAHEAD 4      // frame-0 rows kept ahead of the row being fetched (a smaller value makes the run-time check fire: tested once)
+#define STK_COL_LOOKAHEAD 5      // frame-0 rows kept ahead of the row being fetched (a smaller value makes the run-time check fire: tested once)
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -204,13 +204,16 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
         }
         fast = __builtin_amdgcn_readfirstlane((int)fast) != 0;
         // The ring path needs more: the strip's source columns inside a window of LW pixels, the source row rising by
-        // 0.6 .. 1.4 per template row (at most two new rows per step, three rows of lookahead suffice) and differing by
-        // at most 2.5 rows across the 64 lanes (the ring holds LK rows).
+        // 0.6 .. 1.4 per template row (at most two new rows per step, five rows of lookahead suffice) and differing by
+        // less than a row across the 64 lanes (the ring holds LK rows). ONE pixel / row of guard on every side: the
+        // bounds come from the strip's corners and from lanes 0 and 63 of each row, and an interior lane's coordinate can
+        // round across an integer that the end lanes' do not reach (seen: one frame of 255 differing in 3 % of the runs,
+        // a lane reading a row that was still in flight).
         const float sxmin = __builtin_fminf(__builtin_fminf(cpx[0], cpx[1]), __builtin_fminf(cpx[2], cpx[3]));
         const float sxmax = __builtin_fmaxf(__builtin_fmaxf(cpx[0], cpx[1]), __builtin_fmaxf(cpx[2], cpx[3]));
-        const int xb = __builtin_amdgcn_readfirstlane(((int)__builtin_floorf(sxmin) - 1) & ~3);   // window origin, 16-byte aligned
-        bool ringable = fast & (a.ring != 0) & ((int)__builtin_floorf(sxmax) + 2 - xb <= LW - 1) &
-                        (__builtin_fabsf(cpy[1] - cpy[0]) <= 2.5f) & (__builtin_fabsf(cpy[3] - cpy[2]) <= 2.5f);
+        const int xb = __builtin_amdgcn_readfirstlane(((int)__builtin_floorf(sxmin) - 2) & ~3);   // window origin, 16-byte aligned
+        bool ringable = fast & (a.ring != 0) & ((int)__builtin_floorf(sxmax) + 3 - xb <= LW - 1) &
+                        (__builtin_fabsf(cpy[1] - cpy[0]) <= 0.9f) & (__builtin_fabsf(cpy[3] - cpy[2]) <= 0.9f);
         {
             const float n = (float)(y1 - 1 - y0);
             const float d0 = cpy[2] - cpy[0], d1 = cpy[3] - cpy[1];
@@ -454,10 +457,10 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 coords((float)y0, s0, rw0, fl0);
                 const int iy = (int)fl0.y;
                 const int i0 = __builtin_amdgcn_readlane(iy, 0), i1 = __builtin_amdgcn_readlane(iy, 63);
-                loaded = min(i0, i1) - 1;
+                loaded = min(i0, i1) - 2;                         // the first row loaded is the guard row below the lowest one
                 pI = (const char*)(gI + (ptrdiff_t)(loaded + 1) * rs); pG = (const char*)(gG + 2 * (ptrdiff_t)(loaded + 1) * rs);
                 dst = ring_lds + (unsigned)((loaded + 1) & (LK - 1)) * LROW;
-                const int want = max(i0, i1) + 4;
+                const int want = max(i0, i1) + STK_COL_LOOKAHEAD;
                 while (loaded < want) dma_row();
                 pT = (const char*)(T + (size_t)y0 * a.templ_row_stride); yT = y0;
                 dstT = ring_lds + (LK + 1) * LROW + (unsigned)(yT & (LT - 1)) * 256u;
@@ -466,9 +469,10 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 fetch(y0, ca, ta, ua, ilo, ihi);
             }
             // A transfer issued in step y has landed when step y+2 starts (wait_keep leaves only step y+1's in flight),
-            // so step y fetches what row y+3 will read: frame-0 rows up to ihi(y+1) + 4 (the source row rises by at most
-            // 1.4 per template row) and template row y+3. Nothing a later fetch needs is overwritten: the rows in flight
-            // reach back to ihi(y+1) - 4 at most, the lanes of a row differ by at most 3.
+            // so step y fetches what row y+3 will read: frame-0 rows up to ihi(y+1) + 5 (the source row rises by at most
+            // 1.4 per template row: ihi(y+3) + 1 for the lower taps + 1 of guard <= ihi(y+1) + 5) and template row y+3.
+            // Nothing a later fetch needs is overwritten: the rows in flight reach back to ihi(y+1) - 3 at most, a fetch
+            // reads from ilo - 1 (guard) and the end lanes of a row are at most one row apart.
             // The bounds that make this safe were derived from the strip's corners before the loop; they are also CHECKED, on
             // scalars, row by row: what fetch() is about to read must have landed (`safe`) and must not have been
             // overwritten by anything issued since. A violation poisons one of the strip's sums with a NaN — the solve step
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 wait_keep(prev_issued);
                 safe = before_prev;                               // everything issued before the previous step's transfers has landed
                 fetch(y + 1, nxt, tnxt, unxt, ilo, ihi);
-                violated |= (safe - (ihi + 1)) | (ilo + LK - 1 - loaded);   // a sign bit: read before it landed / after it was overwritten
+                violated |= (safe - (ihi + 2)) | (ilo - 1 + LK - 1 - loaded);   // a sign bit: read (guard row included) before it landed / after it was overwritten
                 before_prev = loaded;
                 issued = 0;
                 if (loaded < ihi + STK_COL_LOOKAHEAD) dma_row();
