@@ -164,6 +164,23 @@ def test_lds_ring_path_is_bit_identical_to_the_gather_path(stacker, w, h, n, str
     assert np.array_equal(ring.cpu().numpy(), gather.cpu().numpy())
 
 
+@pytest.mark.parametrize("motion", [MotionType.Affine, MotionType.Euclidean, MotionType.Translation])
+def test_lds_ring_path_other_motions(stacker, motion):
+    # the same kernel template with one plain accumulator per sum: ring and gather routes must agree bit for bit here too
+    frames, _ = synth.make_stack(4, 1920, 1080, strength=0.5)
+    dev = frames.cuda()
+    p = EccMatchParameters(motion, 30, 1e-4, 5)
+    ring, s_ring = stacker.ecc_match(dev, p, return_stats=True)
+    stacker.set_option("ecc_ring", 0)
+    try:
+        gather, s_gather = stacker.ecc_match(dev, p, return_stats=True)
+    finally:
+        stacker.set_option("ecc_ring", 1)
+    assert [s["iterations"] for s in s_ring] == [s["iterations"] for s in s_gather]
+    assert all(np.array_equal(a["warp"], b["warp"]) for a, b in zip(s_ring, s_gather))
+    assert np.array_equal(ring.cpu().numpy(), gather.cpu().numpy())
+
+
 def test_lds_ring_against_gather_on_random_start_warps(stacker):
     """The ring route decides per column strip whether its source footprint fits (window of 76 columns, lanes at most 2.5
     rows apart, source row rising by 0.6 .. 1.4 per template row, corners with w >= 1/4) and falls back to the gather loop
