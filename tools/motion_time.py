@@ -1,4 +1,4 @@
-"""Timing of ecc_match for the non-homography motion types (variant 3 = pipelined lane-adjacent kernel, 0 = direct)."""
+"""Timing of ecc_match for the non-homography motion types (variant 3 = column-walking kernel, 0 = direct)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
