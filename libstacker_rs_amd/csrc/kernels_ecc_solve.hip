@@ -14,12 +14,17 @@ namespace stk {
 #include "ecc_solve_body.h"
 namespace stk {
 
-// Stand-alone solve: two stages in one launch. The block partials of one slot are 66 x nb doubles (150 KB at 4K) and
-// a single CU pulls that from memory at only a few tens of GB/s, so stage 1 is spread over SOLVE_G workgroups per
-// slot (workgroup g reduces the sums k = g, g + G, ...; each sum by one wavefront in the same fixed order as before),
-// which publish their sums and take a ticket; the workgroup that draws the last ticket runs stage 2 (the normal
-// equations and the loop control) on the 66 published sums. Which workgroup that is does not affect any value.
-constexpr int SOLVE_G = 8;
+// Stand-alone solve, one workgroup per slot: stage 1 reduces the slot's block partials (66 x nb doubles, 150 KB at 4K; each
+// sum by one wavefront in a fixed order), stage 2 runs the normal equations and the loop control on the 66 sums.
+// STK_SOLVE_G > 1 spreads stage 1 over G workgroups per slot that publish their sums and draw tickets, the last drawer
+// running stage 2 (round 1's form, 19 -> 14 us at 4 slots). With ~43 slots in flight the two agent-scope fences of that
+// hand-off cost more than the spread saves — 344 workgroups fencing, 15-23 us of a 32 us launch (-DSTK_SOLVE_TIMING) —
+// and G = 1 needs no hand-off at all: 256-frame 4K step 58.2 ms at G = 8, 57.4 at G = 4, 57.3 at G = 1. Which workgroup
+// reduces a sum does not affect any value.
+#ifndef STK_SOLVE_G
+#define STK_SOLVE_G 1
+#endif
+constexpr int SOLVE_G = STK_SOLVE_G;
 
 __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motion, EccCriteria crit, EccQueue* queue,
                                                        EccFrameResult* results, const float* init_warps) {
@@ -33,7 +38,7 @@ __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motio
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const double* base = a.partials + (size_t)slot * NS * a.nb;
     {
-        constexpr int KB = 3, JB = 5;                       // sums per wave (66 / 8 / 4 rounded up), partials per lane in flight
+        constexpr int KB = (ECC_MAX_SUMS + SOLVE_G * 4 - 1) / (SOLVE_G * 4), JB = 5;   // sums per wave (66 / G / 4 rounded up), partials per lane in flight
         const int nbi = (a.nb + 63) >> 6;
         double acc[KB];
 #pragma unroll
@@ -71,9 +76,11 @@ __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motio
         // that entered an idle slot could come out one ulp or one iteration off, run to run.)
         __shared__ int last_idle;
         if (tid == 0) {
-            const int t = atomicAdd(&a.tickets[slot], 1);
-            last_idle = (t == SOLVE_G - 1);
-            if (last_idle) a.tickets[slot] = 0;
+            if constexpr (SOLVE_G > 1) {
+                const int t = atomicAdd(&a.tickets[slot], 1);
+                last_idle = (t == SOLVE_G - 1);
+                if (last_idle) a.tickets[slot] = 0;
+            } else last_idle = 1;
         }
         __syncthreads();
         if (last_idle && tid == 0) {
@@ -86,17 +93,21 @@ __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motio
 #ifdef STK_SOLVE_TIMING
     const long long t_reduced = wall_clock64();
 #endif
-    __threadfence();                                         // publish this workgroup's sums before its ticket
-    __shared__ int last;
-    __syncthreads();
-    if (tid == 0) {
-        const int t = atomicAdd(&a.tickets[slot], 1);
-        last = (t == SOLVE_G - 1);
-        if (last) a.tickets[slot] = 0;                       // everyone has drawn: reset for the next launch
+    if constexpr (SOLVE_G > 1) {
+        __threadfence();                                     // publish this workgroup's sums before its ticket
+        __shared__ int last;
+        __syncthreads();
+        if (tid == 0) {
+            const int t = atomicAdd(&a.tickets[slot], 1);
+            last = (t == SOLVE_G - 1);
+            if (last) a.tickets[slot] = 0;                   // everyone has drawn: reset for the next launch
+        }
+        __syncthreads();
+        if (!last) return;
+        __threadfence();                                     // see the other workgroups' sums
+    } else {
+        __syncthreads();                                     // one workgroup per slot: its own sums, through its own L1 / L2
     }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();                                         // see the other workgroups' sums
 #ifdef STK_SOLVE_TIMING
     if (tid == 0 && slot == a.slot0) { queue->dbg[0] = t_start; queue->dbg[1] = t_reduced; queue->dbg[2] = wall_clock64(); }
 #endif
