@@ -122,15 +122,27 @@ hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, 
 
 __global__ void ecc_init_kernel(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
                                 const float* init_warps, int ready0) {
-    // one workgroup: the per-frame results by all threads, the queue and the slots (in slot order: slot s starts with
-    // frame s) by thread 0 (a single thread doing everything took 60 us at 31 frames)
+    // one workgroup, everything in parallel: slot s starts with frame s (what handing the frames out one by one from an
+    // empty queue gives), as far as frames are ready; the queue continues behind them
     for (int f = threadIdx.x; f < n_frames; f += blockDim.x) { results[f].status = 3; results[f].iters = 0; results[f].rho = -1; }
-    if (threadIdx.x != 0) return;
-    queue->next_frame = 0; queue->n_frames = n_frames; queue->frames_done = 0; queue->ready = ready0 < 0 ? n_frames : ready0;
-    for (int s = 0; s < n_slots; s++) {
+    const int avail = min(ready0 < 0 ? n_frames : ready0, n_frames);
+    for (int s = threadIdx.x; s < n_slots; s += blockDim.x) {
+        EccSlot* sl = slots + s;
         tickets[s] = 0;
-        slots[s].last_rho = 0;
-        slot_take_next(slots + s, queue, init_warps);
+        sl->last_rho = 0;
+        if (s < avail) {
+            sl->frame = s;
+            sl->iter = 0;
+            for (int k = 0; k < 9; k++) sl->warp[k] = init_warps ? init_warps[(size_t)s * 9 + k] : ((k % 4 == 0) ? 1.f : 0.f);
+            sl->cI = 0; sl->cT = 0;
+            sl->rho = -1;
+        } else {
+            sl->frame = -1;
+        }
+    }
+    if (threadIdx.x == 0) {
+        queue->next_frame = min(avail, n_slots); queue->n_frames = n_frames; queue->frames_done = 0;
+        queue->ready = ready0 < 0 ? n_frames : ready0;
     }
 }
 
