@@ -6,7 +6,7 @@ from libstacker_rs_amd import EccMatchParameters, MotionType, Stacker, synth
 st = Stacker(0)
 p = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
 st.set_option("prep_overlap", 0)
-for n, slots, reps in ((256, 0, 200), (255, 0, 100), (256, 40, 60)):
+for n, slots, reps in ((256, 0, 150), (255, 0, 60), (131, 0, 60)):
     frames, _ = synth.make_stack(n, 3840, 2160, device="cuda")
     st.set_option("ecc_slots", slots)
     ref = None; bad = collections = 0
