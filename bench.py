@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what a float4 stream achieves is measured in the run
 
 WORKLOADS = {
     # name: (width, height, frames in the WHOLE stack, api)
@@ -37,17 +37,18 @@ WORKLOADS = {
     "ecc_1080p": (1920, 1080, 64, "ecc"),               # configs[2]
     "keypoint_1080p": (1920, 1080, 64, "keypoint"),     # configs[1]
     "ecc_small": (640, 480, 8, "ecc"),
-    # BASELINE configs[4] (an extension beyond the reference): 16-bit 4K stack, ORB-seeded ECC refine; 1024 frames in
-    # BASELINE, 256 here so that the u16 stack (12.7 GB) + templates + ORB workspace fit next to each other comfortably
-    "hybrid_4k16": (3840, 2160, 256, "hybrid"),
+    # BASELINE configs[4] (an extension beyond the reference): the 1024-frame 16-bit 4K stack, ORB-seeded ECC refine
+    # (51 GB of u16 frames + 34 GB of templates + the ORB workspace on one GPU; 128 frames per GPU at N = 8)
+    "hybrid_4k16": (3840, 2160, 1024, "hybrid"),
 }
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # default: ~6 s of timed region on the default workload (57 ms per step), long enough for a 5 s utilisation sampler
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ecc_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -66,8 +67,8 @@ def main() -> None:
                     help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the reduce goes through gloo/CPU "
                          "(checks the sharded code path, not a performance number)")
     ap.add_argument("--profile-launches", type=int, default=1,
-                    help="0: no per-launch timing; 1: HIP event pairs around every 3rd ECC iteration launch (roofline.achieved); "
-                         "n > 1: around every n-th")
+                    help="0: no roofline sample; n >= 1: ONE extra step after the timed region (never inside it) with a HIP event "
+                         "pair around every n-th ECC iteration launch (roofline.achieved)")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,11 +125,11 @@ def main() -> None:
     for kv in args.opt:
         k, v = kv.split("=")
         st.set_option(k, int(v))
-    st.set_option("profile", 2 if args.profile_launches else 1)
-    # an event pair around a launch keeps it from being dispatched back to back with its neighbours: bracketing every
-    # launch costs ~5 % of `value`, so every 3rd launch is sampled (3 is coprime with the 4-launch polling chunk)
-    stride = max(1, args.profile_launches if args.profile_launches > 1 else 3)
-    st.set_option("profile_stride", stride)
+    # The timed region runs with stage timers only (profile = 1). An event pair around a launch keeps it from being
+    # dispatched back to back with its neighbours (~5 % of the step if every launch is bracketed), so the per-launch
+    # sample the roofline needs is taken in ONE extra step after the timed region, like the prep kernel's figure.
+    st.set_option("profile", 1)
+    stride = max(1, args.profile_launches)
     # two accumulators: while step k's sum is being reduced over xGMI, step k+1 aligns into the other one
     accs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     cnts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(len(accs))]
@@ -138,7 +139,7 @@ def main() -> None:
     step_no = 0
     totals = [0, 0]                                  # frames folded / dropped in the last finished stack (rank 0)
 
-    agg = {k: 0 for k in ("ecc_iter_ms", "ecc_iter_timed", "ecc_iter_launches", "ecc_slot_iterations", "prep_ms", "align_ms", "warp_ms",
+    agg = {k: 0 for k in ("ecc_iter_launches", "ecc_slot_iterations", "ecc_ring_fallbacks", "prep_ms", "align_ms", "warp_ms",
                           "warp_frames", "warp_launches", "fast_ms", "fast_launches", "fast_pixels")}
     last_stats = None
 
@@ -228,6 +229,29 @@ def main() -> None:
         elapsed = float(tt.item())
     value = n_global * args.steps / elapsed
 
+    # ---- after the timed region: ONE step with an event pair around every `stride`-th ECC iteration launch (rank 0) ----
+    sample = None
+    if rank == 0 and api in ("ecc", "hybrid") and args.profile_launches > 0:
+        st.set_option("profile", 2)
+        st.set_option("profile_stride", stride)
+        try:
+            run_shard(frames, accs[0])
+            t = st.timing()
+            sample = {k: t[k] for k in ("ecc_iter_ms", "ecc_iter_timed", "ecc_iter_launches", "ecc_slot_iterations")}
+        finally:
+            st.set_option("profile", 1)
+    # ---- and what a plain float4 stream achieves on this card in this run: the 1/n scale kernel (read 4 B + write 4 B per
+    # float of a W x H x 3 image), best of 5 by its own HIP-event timer ----
+    stream_gbs = None
+    if rank == 0:
+        best = None
+        for _ in range(5):
+            st.finalize_mean(accs[0], max(totals[0], 1), out)
+            ms = st.timing()["finalize_ms"]
+            best = ms if best is None or ms < best else best
+        if best and best > 0:
+            stream_gbs = 8.0 * 3 * px / best / 1e6
+
     if rank == 0:
         res = result_header(args, value, elapsed, world, scaling, api, W, H, n_global, fpg,
                             "none (1 GPU)" if world == 1 else
@@ -236,27 +260,34 @@ def main() -> None:
         src_b = 3 * px * (2 if depth == 16 else 1)
         kernels = []
         # ---- roofline of the dominant kernel and of the others on the path (live HIP-event timings of THIS run) ----
-        if api in ("ecc", "hybrid") and agg["ecc_iter_timed"] > 0:
+        if sample is not None and sample["ecc_iter_timed"] > 0:
             # ECC iteration kernel: ALGORITHMIC bytes = 16 B/px per frame-iteration (template 4 B + frame-0 image/gx/gy
-            # 12 B); one launch advances up to `slots` frames by one iteration.
-            alg_bytes_total = 16.0 * px * agg["ecc_slot_iterations"]
-            launches = agg["ecc_iter_launches"]                     # every launch of the timed region (incl. drained no-ops)
-            avg_ms = agg["ecc_iter_ms"] / agg["ecc_iter_timed"]     # event-timed sample of them
+            # 12 B); one launch advances up to `slots` frames by one iteration. All figures of this block are
+            # from the sample step (same stack, same schedule as every timed step).
+            alg_bytes_total = 16.0 * px * sample["ecc_slot_iterations"]
+            launches = sample["ecc_iter_launches"]                  # every launch of the sample step (incl. drained no-ops)
+            avg_ms = sample["ecc_iter_ms"] / sample["ecc_iter_timed"]     # mean duration of the event-bracketed ones
             achieved = (alg_bytes_total / launches) / (avg_ms * 1e-3) / 1e9
             traffic, tsrc = pmc_traffic(args, world, "stk::ecc_iter_col_kernel<3>")
             res["roofline"] = {
                 "kernel": "ecc_iter_col_kernel<homography> (ECC iteration pass)",
-                # `bound` names the roofline the figure is priced against (the contract's vocabulary: hbm | mfma); what
-                # actually limits the kernel is VALU issue (~92 instructions per pixel, ablation in DESIGN.md 4.7)
+                # `bound` names the roofline the figure is priced against (the contract's vocabulary: hbm | mfma). `achieved`
+                # is ALGORITHMIC bytes / time: most of those bytes (the frame-0 planes shared by the frames in flight) are
+                # served from L2 / Infinity Cache, the HBM itself sees `traffic`; what limits the kernel is VALU issue.
                 "bound": "hbm", "limiter": "valu-issue",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "peak_achievable": round(stream_gbs, 1) if stream_gbs else None,
+                "peak_achievable_source": "scale_kernel (float4 stream, 4 B read + 4 B write per float of the W x H x 3 image), "
+                                          "best of 5 launches after the timed region, its own HIP-event timer",
+                "frac_of_achievable": round(achieved / stream_gbs, 4) if stream_gbs else None,
                 "traffic": traffic, "traffic_source": tsrc,
-                "avg_launch_ms": round(avg_ms, 5), "launches": launches, "launches_timed": agg["ecc_iter_timed"],
-                "timing": f"HIP event pair around every {stride}{'rd' if stride == 3 else 'th'} launch of the timed region, engine stream "
-                          "(rocprofv3 --kernel-trace mean over ALL launches of the same command: profiles/)",
+                "hbm_frac_of_traffic": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "avg_launch_ms": round(avg_ms, 5), "launches": launches, "launches_timed": sample["ecc_iter_timed"],
+                "timing": f"one extra step AFTER the timed region with a HIP event pair around every {stride}. launch, engine stream "
+                          "(rocprofv3 --kernel-trace mean over ALL launches of the same command: profiles/); `value` is timed without event pairs",
                 "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
-            kernels.append({"kernel": "ecc_iter_col_kernel<homography>", "bytes": "16 B/px/frame-iteration", "GBps": round(achieved, 1),
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(avg_ms * launches / args.steps, 3)})
+            kernels.append({"kernel": "ecc_iter_col_kernel<homography>", "bytes": "16 B/px/frame-iteration (algorithmic; cache-served in part)",
+                            "GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(avg_ms * launches, 3)})
         if agg["warp_ms"] > 0:
             # fused fold: every frame's source read once + the accumulator written once per launch (no read: the launch
             # overwrites); SURVEY 8d's per-frame figure (source + accumulator read + write for EVERY frame) is the unfused cost
@@ -291,6 +322,7 @@ def main() -> None:
             k = kernels[-1]
             res["roofline"] = {"kernel": k["kernel"], "bound": "hbm", "limiter": "valu-issue", "achieved": k["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": k["frac"], "traffic": None,
+                               "peak_achievable": round(stream_gbs, 1) if stream_gbs else None,
                                "timing": "HIP events around the 8 level launches of every ORB batch, engine stream"}
         res["kernels"] = kernels
         its = [s["iterations"] for s in (last_stats or [])[1:]]
@@ -302,6 +334,7 @@ def main() -> None:
             "ecc_iterations_max": int(max(its)) if its else None,
             "synthetic_generation_s": round(gen_s, 1),
             "frames_folded_last_step": totals[0], "frames_dropped_last_step": totals[1],
+            "ecc_ring_fallbacks_per_step": round(agg["ecc_ring_fallbacks"] / args.steps, 3),
         }
         # ---- host-fed: the same stack in PINNED HOST memory, H2D inside the timed region (SURVEY 8d metric ii) ----
         if world == 1 and args.host_fed_steps > 0:
@@ -392,10 +425,8 @@ def cpu_baseline(args, api, frames, W, H):
         oracle.ecc_match(sample, max_count=5000, epsilon=1e-5, gauss_filt_size=5, n_threads=use)
         how = f"frame-parallel OpenMP on {use} threads like the reference's Rayon fold"
     elif api == "hybrid":
-        use, sample = 1, sample[:3]                     # the oracle's hybrid path is a serial Python composition of its stages
-        n_s = len(sample)
-        oracle.hybrid_match(sample)
-        how = "serial composition of the oracle's stages on 1 thread (no frame parallelism)"
+        oracle.hybrid_match(sample, n_threads=use)      # the oracle's stages composed per frame, frames over a thread pool
+        how = f"frame-parallel on {use} threads (one frame per thread: ORB + match + RANSAC + ECC + fold, partial sums combined)"
     else:
         oracle.keypoint_match(sample, n_threads=use)
         how = f"frame-parallel OpenMP on {use} threads like the reference's Rayon fold"

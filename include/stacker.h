@@ -128,6 +128,9 @@ typedef struct {
     double  fast_ms;
     int64_t fast_launches;
     int64_t fast_pixels;
+    /* ECC iteration pass: column strips that started on the per-wave LDS ring, failed its run-time bounds check and were
+     * redone by the gather loop (same bits). 0 on every BASELINE stack; non-zero only costs time. */
+    int64_t ecc_ring_fallbacks;
 } stk_timing;
 
 typedef struct stk_ctx stk_ctx;
@@ -171,6 +174,8 @@ void        stk_host_free(void* p);
  *   "ecc_variant"        ECC pixel-pass kernel: 3 production (default), 0 the direct cross-check version
  *   "ecc_ring"           homography pass: 1 (default) frame-0 rows go through a per-wave LDS ring where a strip allows it,
  *                        0 every tap is gathered from global memory; the results are bit-identical
+ *   "ecc_ring_lookahead" debug: frame-0 rows the ring keeps ahead of the row being fetched (5; 1..4 make its run-time check
+ *                        fire, the strips then fall back to the gather loop: stk_timing.ecc_ring_fallbacks); same bits
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
  *   "kp_workers"         host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
  *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table

@@ -49,7 +49,7 @@ class Timing(C.Structure):
                 ("ecc_slot_iterations", C.c_int64), ("warp_launches", C.c_int64),
                 ("warp_frames", C.c_int64), ("ecc_iter_ms", C.c_double), ("ecc_iter_timed", C.c_int64),
                 ("h2d_ms", C.c_double), ("h2d_bytes", C.c_int64), ("fast_ms", C.c_double), ("fast_launches", C.c_int64),
-                ("fast_pixels", C.c_int64)]
+                ("fast_pixels", C.c_int64), ("ecc_ring_fallbacks", C.c_int64)]
 
 
 # every symbol include/stacker.h declares, with its signature

@@ -60,6 +60,7 @@ struct EccQueue {
     int n_frames;       // number of templates
     int frames_done;
     int ready;          // templates [0, ready) exist; raised by the prep stream while frames are still arriving over PCIe
+    int ring_fallbacks; // strips of the iteration pass that left the LDS ring for the gather loop at run time (stk_timing.ecc_ring_fallbacks)
 #ifdef STK_SOLVE_TIMING
     long long dbg[16];   // wall_clock64 phase deltas of the last solve of slot 0 (10 ns ticks), debug builds only
 #endif
@@ -88,6 +89,8 @@ struct EccIterArgs {
     int* tickets;                // [all slots]: arrival counter of the solve kernel's stage-1 workgroups (self-resetting)
     int slot0;                   // first slot of this launch (0: all slots in one launch)
     int ring;                    // column-walking pass: 1 = frame-0 rows through the per-wave LDS ring where a strip allows it (option ecc_ring)
+    int ring_lookahead;          // frame-0 rows the ring keeps ahead of the row being fetched: 5; lower only to provoke the fallback (option ecc_ring_lookahead)
+    int* ring_fallbacks;         // device counter: strips whose ring bounds failed the run-time check and were redone by the gather loop (EccQueue::ring_fallbacks)
     int units_q, units_r;        // column-walking pass: (column strip, row) units per wave and the remainder (set by launch_ecc_iter)
 };
 

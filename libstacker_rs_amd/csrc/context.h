@@ -58,11 +58,12 @@ struct stk_ctx {
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
     int opt_ecc_ring = 1;         // column-walking ECC pass: frame-0 rows through the per-wave LDS ring (0: always gather from global memory)
+    int opt_ecc_ring_lookahead = 5;   // debug: frame-0 rows the ring keeps ahead (5 = production; less makes the run-time check fire and the strip fall back)
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = production (column-walking homography pass / pipelined affine family), 0 = direct cross-check
     stk_timing timing{};
     hipEvent_t ev[8] = {};
     hipEvent_t poll_ev[2] = {};
-    int* host_done = nullptr;     // pinned, 2 ints
+    int* host_done = nullptr;     // pinned, 16 ints: [0], [1] completion counters of the two chunks in flight, [2] ring fall-back count
     std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;

@@ -10,9 +10,8 @@ namespace stk {
 #ifndef STK_COL_WG
 #define STK_COL_WG 4
 #endif
-#ifndef STK_COL_LOOKAHEAD
-#define STK_COL_LOOKAHEAD 5      // frame-0 rows kept ahead of the row being fetched (a smaller value makes the run-time check fire: tested once)
-#endif
+// frame-0 rows kept ahead of the row being fetched by the LDS ring: EccIterArgs::ring_lookahead, 5 in production (the debug
+// option "ecc_ring_lookahead" lowers it so that the run-time check fires and a test can see the fallback work)
 
 // ---------------------------------------------------------------------------------------------------
 // The row-walking pass this one replaced ran ~97 VALU instructions per pixel (95 in the loop, the rest in row-end and
@@ -172,7 +171,9 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
     const int g = region * 4 + wave;
     int u = g * a.units_q + min(g, a.units_r);
     const int uend = u + a.units_q + (g < a.units_r ? 1 : 0);
+    bool no_ring = false;                     // set for one pass of the loop: the strip failed the ring's run-time check
     while (u < uend) {
+        const int u_strip = u;
         const int col = u / a.th;
         const int y0 = u - col * a.th;
         const int y1 = min(a.th, y0 + (uend - u));
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
         const float sxmin = __builtin_fminf(__builtin_fminf(cpx[0], cpx[1]), __builtin_fminf(cpx[2], cpx[3]));
         const float sxmax = __builtin_fmaxf(__builtin_fmaxf(cpx[0], cpx[1]), __builtin_fmaxf(cpx[2], cpx[3]));
         const int xb = __builtin_amdgcn_readfirstlane(((int)__builtin_floorf(sxmin) - 2) & ~3);   // window origin, 16-byte aligned
-        bool ringable = fast & (a.ring != 0) & ((int)__builtin_floorf(sxmax) + 3 - xb <= LW - 1) &
+        bool ringable = fast & (a.ring != 0) & !no_ring & ((int)__builtin_floorf(sxmax) + 3 - xb <= LW - 1) &
                         (__builtin_fabsf(cpy[1] - cpy[0]) <= 0.9f) & (__builtin_fabsf(cpy[3] - cpy[2]) <= 0.9f);
         {
             const float n = (float)(y1 - 1 - y0);
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 loaded = min(i0, i1) - 2;                         // the first row loaded is the guard row below the lowest one
                 pI = (const char*)(gI + (ptrdiff_t)(loaded + 1) * rs); pG = (const char*)(gG + 2 * (ptrdiff_t)(loaded + 1) * rs);
                 dst = ring_lds + (unsigned)((loaded + 1) & (LK - 1)) * LROW;
-                const int want = max(i0, i1) + STK_COL_LOOKAHEAD;
+                const int want = max(i0, i1) + a.ring_lookahead;
                 while (loaded < want) dma_row();
                 pT = (const char*)(T + (size_t)y0 * a.templ_row_stride); yT = y0;
                 dstT = ring_lds + (LK + 1) * LROW + (unsigned)(yT & (LT - 1)) * 256u;
@@ -475,8 +476,9 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
             // reads from ilo - 1 (guard) and the end lanes of a row are at most one row apart.
             // The bounds that make this safe were derived from the strip's corners before the loop; they are also CHECKED, on
             // scalars, row by row: what fetch() is about to read must have landed (`safe`) and must not have been
-            // overwritten by anything issued since. A violation poisons one of the strip's sums with a NaN — the solve step
-            // then fails the frame (status NaN) instead of a wrong warp going unnoticed.
+            // overwritten by anything issued since. On a violation run_ring returns true: the strip's accumulators are
+            // private to the strip, so the caller clears them and redoes the strip through the gather loop (bit-identical
+            // by construction) and counts the event (stk_timing.ecc_ring_fallbacks; 0 on every BASELINE stack).
             int prev_issued = 1;                                 // (nothing is in flight before the first step)
             int safe = loaded, before_prev = loaded, violated = 0;
             auto step = [&](ColRow& cur, ColTaps& tcur, ColTaps& ucur, ColRow& nxt, ColTaps& tnxt, ColTaps& unxt, int y) {
@@ -486,8 +488,8 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 violated |= (safe - (ihi + 2)) | (ilo - 1 + LK - 1 - loaded);   // a sign bit: read (guard row included) before it landed / after it was overwritten
                 before_prev = loaded;
                 issued = 0;
-                if (loaded < ihi + STK_COL_LOOKAHEAD) dma_row();
-                if (loaded < ihi + STK_COL_LOOKAHEAD) dma_row();
+                if (loaded < ihi + a.ring_lookahead) dma_row();
+                if (loaded < ihi + a.ring_lookahead) dma_row();
                 dma_templ();
                 prev_issued = issued;
                 blend(cur, tcur, ucur, bl); accumulate(std::true_type{}, std::false_type{}, cur, bl, y);
@@ -497,10 +499,21 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 if (y + 1 < y1) step(cb, tb, ub, ca, ta, ua, y + 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in the ring after the strip (it is reused)
-            if (violated < 0) { if constexpr (HOMOGRAPHY) s_x = __builtin_nanf(""); else accp[NS - 1] = __builtin_nanf(""); }
             if constexpr (HOMOGRAPHY) s_mf += (float)(y1 - y0);
+            return violated < 0;
         };
-        if (ringable) run_ring(); else if (fast) run(std::true_type{}); else run(std::false_type{});
+        if (ringable) {
+            if (run_ring()) {
+                // the ring's bounds did not hold on this strip (a local source-row rate the corner test cannot see): take
+                // the strip again, from the top of the loop, through the gather route
+                clear();
+                u = u_strip;
+                no_ring = true;
+                if (lane == 0) atomicAdd(a.ring_fallbacks, 1);
+                continue;
+            }
+        } else if (fast) run(std::true_type{}); else run(std::false_type{});
+        no_ring = false;
 
         // flush the strip: apply the powers of X, sum over the 64 lanes, add to the f64 totals
         {

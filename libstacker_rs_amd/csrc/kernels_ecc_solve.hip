@@ -141,7 +141,7 @@ __global__ void ecc_init_kernel(EccSlot* slots, int n_slots, int* tickets, EccQu
         }
     }
     if (threadIdx.x == 0) {
-        queue->next_frame = min(avail, n_slots); queue->n_frames = n_frames; queue->frames_done = 0;
+        queue->next_frame = min(avail, n_slots); queue->n_frames = n_frames; queue->frames_done = 0; queue->ring_fallbacks = 0;
         queue->ready = ready0 < 0 ? n_frames : ready0;
     }
 }

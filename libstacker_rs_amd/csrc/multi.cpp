@@ -85,7 +85,9 @@ void multi_destroy(stk_ctx* ctx) {
     for (size_t i = 0; i < ms->comms.size(); i++) if (ms->comms[i]) (void)ms->api.CommDestroy(ms->comms[i]);
     for (size_t i = 0; i < ms->members.size(); i++) {
         (void)hipSetDevice(ms->devices[i]);
-        ms->sums[i].release(); ms->counts[i].release(); ms->stage[i].release();
+        // (the buffers are sized for all devices before the first member is created: a failed stk_create_multi arrives
+        // here with fewer members than buffers, never the other way round)
+        if (i < ms->sums.size()) { ms->sums[i].release(); ms->counts[i].release(); ms->stage[i].release(); }
         if (i > 0) stk_destroy(ms->members[i]);
     }
     (void)hipSetDevice(ctx->device);
@@ -190,11 +192,15 @@ stk_status multi_match(stk_ctx* ctx, int kind, const stk_frames* frames, const s
             HIP_TRY(hipStreamSynchronize(ms->members[r]->stream));      // c2 is a stack temporary
         }
         NCCL_TRY(ms->api.GroupStart());
-        for (int r = 0; r < world; r++) {
-            NCCL_TRY(ms->api.Reduce(ms->sums[r].p, ms->sums[r].p, nel, ncclFloat32, ncclSum, 0, ms->comms[r], ms->members[r]->stream));
-            NCCL_TRY(ms->api.Reduce(ms->counts[r].p, ms->counts[r].p, 2, ncclInt32, ncclSum, 0, ms->comms[r], ms->members[r]->stream));
+        ncclResult_t gr = ncclSuccess;                               // a failure inside the group must still close it
+        for (int r = 0; r < world && gr == ncclSuccess; r++) {
+            gr = ms->api.Reduce(ms->sums[r].p, ms->sums[r].p, nel, ncclFloat32, ncclSum, 0, ms->comms[r], ms->members[r]->stream);
+            if (gr == ncclSuccess)
+                gr = ms->api.Reduce(ms->counts[r].p, ms->counts[r].p, 2, ncclInt32, ncclSum, 0, ms->comms[r], ms->members[r]->stream);
         }
-        NCCL_TRY(ms->api.GroupEnd());
+        const ncclResult_t ge = ms->api.GroupEnd();
+        if (gr != ncclSuccess || ge != ncclSuccess)
+            return fail(ctx, STK_HIP_ERROR, std::string("ncclReduce of the accumulators: ") + ms->api.GetErrorString(gr != ncclSuccess ? gr : ge));
         for (int r = world - 1; r >= 0; r--) {
             (void)hipSetDevice(ms->devices[r]);
             HIP_TRY(hipStreamSynchronize(ms->members[r]->stream));
@@ -238,13 +244,13 @@ stk_status stk_create_multi(int32_t n_devices, const int32_t* device_ids, stk_ct
     MultiState* ms = new MultiState();
     ctx->multi = ms;
     ms->members.push_back(ctx); ms->devices.push_back(device_ids[0]);
+    ms->sums.resize(n_devices); ms->counts.resize(n_devices); ms->stage.resize(n_devices);
     for (int i = 1; i < n_devices; i++) {
         stk_ctx* c = nullptr;
-        if ((st = stk_create(device_ids[i], &c))) { stk_destroy(ctx); return st; }
+        if ((st = stk_create(device_ids[i], &c))) { stk_destroy(ctx); return st; }      // e.g. a device id the node does not have
         ms->members.push_back(c); ms->devices.push_back(device_ids[i]);
         for (int k = 0; k < i; k++) if (device_ids[k] == device_ids[i]) ms->distinct = false;
     }
-    ms->sums.resize(n_devices); ms->counts.resize(n_devices); ms->stage.resize(n_devices);
     if (ms->distinct) {
         if ((st = load_rccl(ctx, ms->api))) { stk_destroy(ctx); return st; }
         ms->comms.assign(n_devices, nullptr);
@@ -289,9 +295,12 @@ stk_status stk_rccl_selftest(stk_ctx* ctx, int64_t count) {
     }
     if (!result) {
         ncclResult_t nr = ms->api.GroupStart();
-        for (int r = 0; r < world && nr == ncclSuccess; r++)
-            nr = ms->api.Reduce(bufs[r].p, bufs[r].p, (size_t)count, ncclFloat32, ncclSum, 0, ms->comms[r], ms->members[r]->stream);
-        if (nr == ncclSuccess) nr = ms->api.GroupEnd();
+        if (nr == ncclSuccess) {
+            for (int r = 0; r < world && nr == ncclSuccess; r++)
+                nr = ms->api.Reduce(bufs[r].p, bufs[r].p, (size_t)count, ncclFloat32, ncclSum, 0, ms->comms[r], ms->members[r]->stream);
+            const ncclResult_t ge = ms->api.GroupEnd();              // closed on the error path too
+            if (nr == ncclSuccess) nr = ge;
+        }
         if (nr != ncclSuccess) result = fail(ctx, STK_HIP_ERROR, std::string("rccl selftest: ") + ms->api.GetErrorString(nr));
     }
     for (int r = 0; r < world && !result; r++) {

@@ -156,6 +156,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
     else if (n == "ecc_ring") ctx->opt_ecc_ring = value != 0;
+    else if (n == "ecc_ring_lookahead") { if (value < 1 || value > 5) return fail(ctx, STK_INVALID_PARAMS, "ecc_ring_lookahead must be 1..5"); ctx->opt_ecc_ring_lookahead = (int)value; }
     else if (n == "ecc_variant") { if (value != 0 && value != 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 3 (production) or 0 (direct cross-check)"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
@@ -274,11 +275,13 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     a.n_slots = pl.n_slots;
     a.nb = pl.nb;
     a.ring = ctx->opt_ecc_ring;
+    a.ring_lookahead = ctx->opt_ecc_ring_lookahead;
     a.partials = ctx->partials.as<double>();
     a.sums = a.partials + (size_t)pl.n_slots * pl.nb * pl.nsums;
     a.tickets = reinterpret_cast<int*>(a.sums + (size_t)pl.n_slots * ECC_MAX_SUMS);
     EccQueue* q = ctx->queue.as<EccQueue>();
     EccFrameResult* r = ctx->results.as<EccFrameResult>();
+    a.ring_fallbacks = &q->ring_fallbacks;
     a.slot0 = 0;
     HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, a.tickets, q, pl.n_templates, r, init_warps_dev, ctx->stream, feed ? 0 : -1));
     int fed = feed ? 0 : pl.n_templates;
@@ -351,7 +354,9 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
         }
     }
     HIP_TRY(hipMemcpyAsync(res.data(), r, sizeof(EccFrameResult) * pl.n_templates, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->host_done[2], &q->ring_fallbacks, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->timing.ecc_ring_fallbacks += ctx->host_done[2];
 #ifdef STK_SOLVE_TIMING
     { EccQueue hq; (void)hipMemcpy(&hq, q, sizeof(hq), hipMemcpyDeviceToHost);
       fprintf(stderr, "SOLVE_DBG stage1 %lld ticket %lld sums %lld stats %lld lu %lld iph %lld tail %lld (x10ns)\n", hq.dbg[1] - hq.dbg[0], hq.dbg[2] - hq.dbg[1],

@@ -263,7 +263,7 @@ def sharpness(grey, metric: int, ksize: int = 0) -> float:
 
 
 def hybrid_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0, match_keep_ratio: float = 0.80,
-                 match_ratio: float = 0.9, max_count=5000, epsilon=1e-5, gauss_filt_size=5):
+                 match_ratio: float = 0.9, max_count=5000, epsilon=1e-5, gauss_filt_size=5, n_threads: int = 1):
     """BASELINE configs[4] (an extension beyond the reference), composed from the oracle's stages: ORB + RANSAC
     homography on the 8-bit grey ((grey16 + 128) / 257 for 16-bit frames) seeds findTransformECC (Homography) on float(grey);
     fold with alpha = 1/65535 (16-bit) or 1/255. Returns (image, warps [n,3,3] f32, iterations, seeds [n,3,3] f32)."""
@@ -271,17 +271,18 @@ def hybrid_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0, 
     frames = [np.ascontiguousarray(f) for f in frames]
     n = len(frames)
     is16 = frames[0].dtype == np.uint16
-    greys = [grey(f) for f in frames]
-    g8 = [((g.astype(np.uint32) + 128) // 257).astype(np.uint8) if is16 else g for g in greys]
-    gf = [g.astype(np.float32) if is16 else g for g in greys]          # ECC input: float(grey16) / the 8-bit grey
-    kp0, de0 = orb_detect_and_compute(g8[0])
+    def greys_of(i):                                                    # (ORB input, ECC input) of frame i
+        g = grey(frames[i])
+        return (((g.astype(np.uint32) + 128) // 257).astype(np.uint8), g.astype(np.float32)) if is16 else (g, g)
+    g8_0, gf_0 = greys_of(0)                                            # ECC input: float(grey16) / the 8-bit grey
+    kp0, de0 = orb_detect_and_compute(g8_0)
     warps = np.zeros((n, 3, 3), np.float32); warps[0] = np.eye(3)
     seeds = np.zeros((n, 3, 3), np.float32); seeds[:] = np.eye(3)
     iters = np.zeros(n, np.int32)
     alpha = 1.0 / 65535.0 if is16 else 1.0 / 255.0
-    acc = warp_frame(frames[0], np.eye(3), alpha=alpha)
-    for i in range(1, n):
-        kp, de = orb_detect_and_compute(g8[i])
+    def align(i):
+        g8_i, gf_i = greys_of(i)
+        kp, de = orb_detect_and_compute(g8_i)
         ms = []
         if len(kp0):
             knn = bf_knn2_hamming(de0, de)
@@ -300,9 +301,33 @@ def hybrid_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0, 
             if H is not None and abs(np.linalg.det(H)) >= 1e-6 and abs(H[2, 2]) > 1e-12:
                 seeds[i] = (H / H[2, 2]).astype(np.float32)
                 seeds[i][2, 2] = 1.0
-        rc, W, rho, its = find_transform_ecc(gf[i], gf[0], seeds[i], MOTION_HOMOGRAPHY, max_count, epsilon, gauss_filt_size)
+        rc, W, rho, its = find_transform_ecc(gf_i, gf_0, seeds[i], MOTION_HOMOGRAPHY, max_count, epsilon, gauss_filt_size)
         if rc:
             raise RuntimeError("hybrid_match: findTransformECC rc=%d on frame %d" % (rc, i))
         warps[i], iters[i] = W, its
-        acc = warp_frame(frames[i], W.astype(np.float64), alpha=alpha, acc=acc)
+        return W
+
+    if n_threads <= 1:
+        acc = warp_frame(frames[0], np.eye(3), alpha=alpha)
+        for i in range(1, n):
+            acc = warp_frame(frames[i], align(i).astype(np.float64), alpha=alpha, acc=acc)
+        return scale(acc, n), warps, iters, seeds
+    # frame-parallel like the reference's Rayon fold (lib.rs:188-335): every worker aligns and folds a contiguous run of
+    # frames into its own accumulator (the C stages release the GIL), the partial sums are added in run order
+    from concurrent.futures import ThreadPoolExecutor
+    n_threads = max(1, min(n_threads, n))
+    bounds = [1 + (n - 1) * k // n_threads for k in range(n_threads + 1)]
+    runs = [range(bounds[k], bounds[k + 1]) for k in range(n_threads)]
+
+    def fold_run(k):
+        part = warp_frame(frames[0], np.eye(3), alpha=alpha) if k == 0 else None
+        for i in runs[k]:
+            W = align(i).astype(np.float64)
+            part = warp_frame(frames[i], W, alpha=alpha, acc=part) if part is not None else warp_frame(frames[i], W, alpha=alpha)
+        return part
+    with ThreadPoolExecutor(n_threads) as ex:
+        parts = [p for p in ex.map(fold_run, range(n_threads)) if p is not None]
+    acc = parts[0]
+    for p in parts[1:]:
+        acc = acc + p
     return scale(acc, n), warps, iters, seeds

@@ -42,7 +42,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_ffi.EccParams) == 32
     assert C.sizeof(_ffi.FrameStats) == 8 + 8 + 16 + 72
     assert C.sizeof(_ffi.Frames) == 8 + 6 * 4 + 8
-    assert C.sizeof(_ffi.Timing) == 15 * 8
+    assert C.sizeof(_ffi.Timing) == 16 * 8
 
 
 def test_no_gpu_fails_loudly_not_silently():

@@ -181,6 +181,37 @@ def test_lds_ring_path_other_motions(stacker, motion):
     assert np.array_equal(ring.cpu().numpy(), gather.cpu().numpy())
 
 
+def test_lds_ring_run_time_check_falls_back_to_the_gather_loop(stacker):
+    """The ring's safety rests on bounds derived from a strip's corners plus a scalar check, row by row, that what a fetch
+    reads has landed and has not been overwritten. A strip that fails the check is redone by the gather loop (its
+    accumulators are private and cleared) and counted — it used to poison a sum with NaN and fail the whole stack with
+    OpenCV's NaN error. The debug option ecc_ring_lookahead = 1 makes the check fire on ordinary strips: the results must
+    still equal the gather route's bit for bit, and the production lookahead must count no fall-back at all."""
+    frames, _ = synth.make_stack(5, 1920, 1080, strength=1.0)
+    dev = frames.cuda()
+    ref, s_ref = stacker.ecc_match(dev, PARAMS, return_stats=True)
+    assert stacker.timing()["ecc_ring_fallbacks"] == 0
+    stacker.set_option("ecc_ring_lookahead", 1)
+    try:
+        out, s_out = stacker.ecc_match(dev, PARAMS, return_stats=True)
+        n_fallbacks = stacker.timing()["ecc_ring_fallbacks"]
+    finally:
+        stacker.set_option("ecc_ring_lookahead", 5)
+    assert n_fallbacks > 0, "lookahead 1 did not provoke the run-time check: the test exercises nothing"
+    assert [s["iterations"] for s in s_out] == [s["iterations"] for s in s_ref]
+    assert all(np.array_equal(a["warp"], b["warp"]) for a, b in zip(s_out, s_ref))
+    assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy())
+    stacker.set_option("ecc_ring", 0)
+    try:
+        gather = stacker.ecc_match(dev, PARAMS)
+        assert stacker.timing()["ecc_ring_fallbacks"] == 0
+    finally:
+        stacker.set_option("ecc_ring", 1)
+    assert np.array_equal(gather.cpu().numpy(), ref.cpu().numpy())
+    with pytest.raises(Exception):
+        stacker.set_option("ecc_ring_lookahead", 0)
+
+
 def test_lds_ring_against_gather_on_random_start_warps(stacker):
     """The ring route decides per column strip whether its source footprint fits (window of 76 columns, lanes at most 2.5
     rows apart, source row rising by 0.6 .. 1.4 per template row, corners with w >= 1/4) and falls back to the gather loop

@@ -68,6 +68,44 @@ def test_ecc_4k_ground_truth_oracle_and_determinism(stacker, stack4k):
     assert np.array_equal(dev3.cpu().numpy(), host)
 
 
+def test_ecc_4k_stacked_image_matches_the_oracle(stacker, stack4k):
+    """North star: "stacked output within 1e-4 relative" at the metric's frame size. ecc_match on 4 x 4K frames end to end
+    (prep, ECC, warpPerspective, fold, 1/n) against the oracle's ecc_match: iteration counts, warps (<= 0.05 px) and the
+    stacked PIXELS — max |a - b| / max(|b|, 1e-3) over the pixels >= 2 px inside every warped border; the bar is 1e-4 or,
+    where one f32 ulp of the warp matrix is worth more than that (x ~ 3800: 2.3e-4 px), 3 x the oracle's own 1-ulp floor
+    (conftest.assert_ecc_stack_close prints both numbers; DESIGN.md section 2 carries them)."""
+    frames, _ = stack4k
+    sub = frames[:4]
+    host = [f for f in sub.cpu().numpy()]
+    out, stats = stacker.ecc_match(sub, ECC, return_stats=True)
+    assert stacker.timing()["ecc_ring_fallbacks"] == 0
+    ref, warps, iters = oracle.ecc_match(host, max_count=5000, epsilon=1e-5, gauss_filt_size=5, n_threads=4)
+    for i in range(1, 4):
+        assert abs(stats[i]["iterations"] - int(iters[i])) <= 1
+        assert synth.corner_error(stats[i]["warp"], warps[i], W4K, H4K) <= 0.05
+    assert_ecc_stack_close(out.cpu().numpy(), ref, host, warps, label="4 x 3840x2160",
+                           iters=[s["iterations"] for s in stats[1:]], iters_ref=[int(k) for k in iters[1:]])
+
+
+def test_warp_accumulate_4k_u8_vs_oracle(stacker, stack4k):
+    # the fold's kernel at the metric's size on a non-identity homography (rotation, scale, perspective, sub-pixel shift):
+    # u8 fast path vs the oracle's warp_frame with the same matrix, <= 1e-6 abs (identical f32 op sequence)
+    frames, G = stack4k
+    f = frames[3]
+    th = np.radians(0.4)
+    C = np.array([[1, 0, W4K / 2], [0, 1, H4K / 2], [0, 0, 1.0]])
+    M = C @ np.array([[1.003 * np.cos(th), -1.003 * np.sin(th), 6.37], [1.003 * np.sin(th), 1.003 * np.cos(th), -4.81],
+                      [1.1e-6, -0.7e-6, 1.0]]) @ np.linalg.inv(C)
+    fh = f.cpu().numpy()
+    for mat in (M, np.asarray(G[3], np.float64)):
+        got = stacker.warp_accumulate(f, mat).cpu().numpy()
+        ref = oracle.warp_frame(fh, mat)
+        assert np.max(np.abs(got - ref)) <= 1e-6
+    base = oracle.convert_f32(frames[0].cpu().numpy())               # and folded onto an existing accumulator
+    got = stacker.warp_accumulate(f, M, acc=torch.from_numpy(base.copy()).cuda()).cpu().numpy()
+    assert np.max(np.abs(got - oracle.warp_frame(fh, M, acc=base.copy()))) <= 1e-6
+
+
 def test_ecc_4k_shard_invariance(stacker, stack4k):
     # 8 moving frames over 2 ranks: every frame is summed over its fixed workgroup partition (288 per 4K frame), so its
     # warp is bit-identical to the single-GPU run for any split.

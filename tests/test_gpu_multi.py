@@ -103,3 +103,13 @@ def test_multi_context_on_files(stacker, multi, tmp_path):
     d1, k1 = stacker.keypoint_match_files(paths, KP)
     d2, k2 = multi.keypoint_match_files(paths, KP)
     assert d1 == d2 and np.max(np.abs(k1 - k2)) <= 1e-6
+
+
+def test_create_multi_with_a_device_the_node_does_not_have():
+    # member creation failing half-way used to index the not-yet-sized accumulator vectors in the clean-up
+    from libstacker_rs_amd import HipError
+    for ids in ([0, 9999], [0, 0, 9999], [9999, 0]):
+        with pytest.raises(HipError):
+            Stacker(devices=ids)
+    s = Stacker(devices=[0, 0])                          # and the library is still usable afterwards
+    s.close()
