@@ -115,6 +115,23 @@ class _Marshalled:
     """Pointers + geometry of a frame stack, keeping the owners alive."""
 
     def __init__(self, frames):
+        if _is_torch(frames) and frames.dim() == 4 and frames.is_contiguous() and frames.shape[0] > 0 \
+                and str(frames.dtype).replace("torch.", "") in _DEPTH:
+            # one tensor holding the whole stack: the pointers are an arithmetic progression — no per-frame Python work
+            # (unbinding 256 frames cost ~2 ms per call, 3 % of a 57 ms stack)
+            self.keep = [frames]
+            self.n = int(frames.shape[0])
+            self.location = DEVICE if frames.is_cuda else HOST
+            self.torch_device = frames.device if frames.is_cuda else None
+            self.devices = {frames.device} if frames.is_cuda else set()
+            self.h, self.w, self.c = (int(v) for v in frames.shape[1:])
+            self.depth = _DEPTH[str(frames.dtype).replace("torch.", "")]
+            step = self.h * self.w * self.c * (self.depth // 8)
+            addr = (frames.data_ptr() + np.arange(self.n, dtype=np.uint64) * np.uint64(step)).astype(np.uint64)
+            self.ptr_arr = (C.c_void_p * self.n).from_buffer_copy(addr.tobytes())
+            self.c_frames = _ffi.Frames(C.cast(self.ptr_arr, C.POINTER(C.c_void_p)), self.n, self.w, self.h, self.c,
+                                        self.depth, self.location, 0)
+            return
         if _is_torch(frames) and frames.dim() == 4:
             frames = list(frames.unbind(0))
         elif isinstance(frames, np.ndarray) and frames.ndim == 4:

@@ -97,8 +97,14 @@ struct EccIterArgs {
 struct WarpFrame {
     const void* src;
     float  M[9];                 // destination -> source map, f32 (subpixel_bits == 0)
+    int    flags;                // WARPFRAME_*: set by warp_fold for the destination rectangle of the launch
     double Md[9];                // same in double (classic quantised path)
 };
+// over the whole destination rectangle |W| lies in [2^-36, 2^36] and |X|, |Y| (before the division) below 2^36: the range
+// in which an IEEE f32 division applies no scaling, so X / W and Y / W may share one reciprocal chain (kernels_warp.hip)
+constexpr int WARPFRAME_DIV_IN_RANGE = 1;
+// the frame's base address and its row stride are multiples of 4: the u8 fast path may gather dword-aligned 12-byte windows
+constexpr int WARPFRAME_SRC_ALIGNED4 = 2;
 
 struct WarpArgs {
     const WarpFrame* frames;

@@ -64,6 +64,8 @@ struct stk_ctx {
     hipEvent_t ev[8] = {};
     hipEvent_t poll_ev[2] = {};
     int* host_done = nullptr;     // pinned, 16 ints: [0], [1] completion counters of the two chunks in flight, [2] ring fall-back count
+    const void* ref_zeroed_ptr = nullptr;   // the frame-0 planes' zero border exists for this buffer and geometry (ecc_prepare_reference)
+    int ref_zeroed_w = 0, ref_zeroed_h = 0;
     std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
@@ -92,7 +94,7 @@ using stk::WarpFrame;
 size_t frame_row_bytes(const stk_frames* f);
 stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<const void*>& dev);
 stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr);
-stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
+stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
                      size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
                      int is_affine, float* acc, size_t acc_stride_floats, int accumulate);
 void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine);

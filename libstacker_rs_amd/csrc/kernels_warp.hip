@@ -135,12 +135,22 @@ __global__ __launch_bounds__(256) void warp_accumulate_kernel(WarpArgs a) {
 //     with v_cvt_f32_ubyteN (extract + convert in one instruction);
 //   * the frame loop is unrolled by WU: all 2*WU loads of a group are issued before the first is consumed;
 //   * the accumulator (12 B/px) is read once (if accumulating) and written once per launch, whatever the frame count.
+// Round 3, same bits again, ~70 -> ~50 VALU instructions per pixel and frame:
+//   * the range test that licenses the shared reciprocal chain is made ONCE per frame on the host (warp_fold: W, X, Y are
+//     affine in (x, y), so their extremes over the destination rectangle sit at its corners) and reaches the kernel as a
+//     scalar flag; only frames that fail it take the per-pixel test;
+//   * the twelve taps are converted straight out of the loaded dwords (v_cvt_f32_ubyte0..3, no shifts) into register
+//     PAIRS — (B, G) of a tap, and R of the two rows — so that the x alpha multiplies (12 -> 6 v_pk_mul_f32), the
+//     horizontal and vertical lerps (18 -> 10: v_pk_add_f32 with a negated operand + v_pk_fma_f32) and the running sums
+//     (3 -> 2) are packed. Per component these are the generic kernel's operations in the generic kernel's order.
 // -----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
     uint64_t v;
     __builtin_memcpy(&v, p, 8);
     return v;
 }
+
+struct Tap12 { uint32_t a, b, c; };   // 12 bytes of a row: u8 kernel: an aligned window; u16 kernel: B0 G0 | R0 B1 | G1 R1
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
@@ -168,14 +178,16 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
     const int y = blockIdx.y * (4 / WX) + wave / WX;
     if (x >= a.dw || y >= a.dh) return;
     float* accp = a.acc + (size_t)y * a.acc_stride + (size_t)x * 3;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (a.accumulate) { s0 = accp[0]; s1 = accp[1]; s2 = accp[2]; }
+    f32x2 s01 = {0.f, 0.f};                   // (B, G) running sums as a register pair, R apart
+    float s2 = 0.f;
+    if (a.accumulate) { s01.x = accp[0]; s01.y = accp[1]; s2 = accp[2]; }
     const float fx = (float)x, fy = (float)y;
     const int sw = a.sw, sh = a.sh;
     const int stride32 = (int)a.src_stride;
     const float alpha = a.alpha, b0 = a.bv[0], b1 = a.bv[1], b2 = a.bv[2];
 
 #define STK_CH(d, sft) ((float)(((d) >> (sft)) & 0xffu) * alpha)
+#define STK_UB(d, k) ((float)(((d) >> (8 * (k))) & 0xffu))                           /* v_cvt_f32_ubyte<k> */
 #define STK_LERP(p00, p01, p10, p11)                                                   \
     __builtin_fmaf(ay[u], __builtin_fmaf(ax[u], (p11) - (p10), (p10)) - __builtin_fmaf(ax[u], (p01) - (p00), (p00)), \
                    __builtin_fmaf(ax[u], (p01) - (p00), (p00)))
@@ -193,13 +205,17 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
                 const float W = __builtin_fmaf(fr->M[6], fx, __builtin_fmaf(fr->M[7], fy, fr->M[8]));
                 // |W| in [2^-40, 2^40] (it is ~1 for any real homography) and |X|, |Y| < 2^40: the range in which the IEEE
                 // expansion applies no scaling, so the shared chain returns the same bits
-                const float aw = __builtin_fabsf(W);
-                const bool safe = (__builtin_fmaxf(__builtin_fmaxf(aw, __builtin_fabsf(XY.x)), __builtin_fabsf(XY.y)) < 1.0995116e12f) &
-                                  (aw > 9.094947e-13f);
-                if (__all(safe)) XY = div2_shared(XY, W);       // finite operands in range: finite quotients
+                if (fr->flags & WARPFRAME_DIV_IN_RANGE) XY = div2_shared(XY, W);     // decided per frame on the host (uniform branch)
                 else {
-                    XY.x = XY.x / W; XY.y = XY.y / W;
-                    fin = (__builtin_fabsf(XY.x) < 1e9f) & (__builtin_fabsf(XY.y) < 1e9f);
+                    const float aw = __builtin_fabsf(W);
+                    // (compares, not max: a NaN operand must fail the test, v_max would drop it)
+                    const bool safe = (aw < 1.0995116e12f) & (__builtin_fabsf(XY.x) < 1.0995116e12f) & (__builtin_fabsf(XY.y) < 1.0995116e12f) &
+                                      (aw > 9.094947e-13f);
+                    if (__all(safe)) XY = div2_shared(XY, W);   // finite operands in range: finite quotients
+                    else {
+                        XY.x = XY.x / W; XY.y = XY.y / W;
+                        fin = (__builtin_fabsf(XY.x) < 1e9f) & (__builtin_fabsf(XY.y) < 1e9f);
+                    }
                 }
             } else {
                 fin = (__builtin_fabsf(XY.x) < 1e9f) & (__builtin_fabsf(XY.y) < 1e9f);
@@ -222,22 +238,42 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
                 const uint8_t* __restrict__ src = (const uint8_t*)a.frames[min(f0 + u, a.n_frames - 1)].src;
                 // one frame is < 2 GiB (checked by the launcher): 32-bit offsets on the frame's uniform base pointer
                 unsigned o = (unsigned)(__mul24(iy[u], stride32) + ix[u] * 3);      // rows < 2^24, row stride < 2^24 bytes
-#ifdef STK_WARP_ABLATE
-                if (a.tune & 0x100) o &= ~7u;                                         // ablation: aligned gathers (wrong pixels)
-                if (a.tune & 0x200) { raw0[u] = o; raw1[u] = o + 1; continue; }       // ablation: no loads at all
-                if (a.tune & 0x400) { raw0[u] = *(const uint32_t*)(src + (o & ~3u)); raw1[u] = *(const uint32_t*)(src + ((o + stride32) & ~3u)); continue; }
-#endif
-                raw0[u] = load_u64_unaligned(src + o);
-                raw1[u] = load_u64_unaligned(src + o + (unsigned)stride32);
+                const uint8_t* __restrict__ src1 = src + (unsigned)stride32;        // uniform: the second row's base stays in SGPRs
+                if (a.frames[min(f0 + u, a.n_frames - 1)].flags & WARPFRAME_SRC_ALIGNED4) {
+                    // The L1's address pipeline, not VALU issue, is what bounds this kernel (round 3: 20 % fewer VALU
+                    // instructions changed nothing): an 8-byte gather at a 3-byte lane stride straddles dword boundaries in
+                    // most lanes. A 12-byte window from the dword-aligned address below covers the 6 bytes wherever they
+                    // start (offset 0..3), and v_alignbyte moves them into place: 1.23 -> 1.01 ms per 64 4K frames. The
+                    // window ends at most 11 bytes behind `o`: inside the frame, the interior test keeps a row to spare.
+                    const unsigned oa = o & ~3u, sh = o & 3u;
+                    Tap12 t0, t1;
+                    __builtin_memcpy(&t0, __builtin_assume_aligned(src + oa, 4), 12);
+                    __builtin_memcpy(&t1, __builtin_assume_aligned(src1 + oa, 4), 12);
+                    // (the flag also says that the row stride is a multiple of 4: both rows' windows are dword-aligned)
+                    const uint32_t l0 = __builtin_amdgcn_alignbyte(t0.b, t0.a, sh), h0 = __builtin_amdgcn_alignbyte(t0.c, t0.b, sh);
+                    const uint32_t l1 = __builtin_amdgcn_alignbyte(t1.b, t1.a, sh), h1 = __builtin_amdgcn_alignbyte(t1.c, t1.b, sh);
+                    raw0[u] = (uint64_t)l0 | ((uint64_t)h0 << 32);
+                    raw1[u] = (uint64_t)l1 | ((uint64_t)h1 << 32);
+                } else {
+                    raw0[u] = load_u64_unaligned(src + o);
+                    raw1[u] = load_u64_unaligned(src1 + o);
+                }
             }
 #pragma unroll
             for (int u = 0; u < WU; u++) {
                 if (f0 + u < a.n_frames) {
-                    const uint32_t a0 = (uint32_t)raw0[u], a1 = (uint32_t)(raw0[u] >> 24);
-                    const uint32_t c0 = (uint32_t)raw1[u], c1 = (uint32_t)(raw1[u] >> 24);
-                    s0 = s0 + STK_LERP(STK_CH(a0, 0), STK_CH(a1, 0), STK_CH(c0, 0), STK_CH(c1, 0));
-                    s1 = s1 + STK_LERP(STK_CH(a0, 8), STK_CH(a1, 8), STK_CH(c0, 8), STK_CH(c1, 8));
-                    s2 = s2 + STK_LERP(STK_CH(a0, 16), STK_CH(a1, 16), STK_CH(c0, 16), STK_CH(c1, 16));
+                    // a row's two taps are bytes B0 G0 R0 B1 | G1 R1 . . of the (lo, hi) dwords
+                    const uint32_t l0 = (uint32_t)raw0[u], h0 = (uint32_t)(raw0[u] >> 32);
+                    const uint32_t l1 = (uint32_t)raw1[u], h1 = (uint32_t)(raw1[u] >> 32);
+                    const f32x2 al2 = {alpha, alpha}, ax2 = {ax[u], ax[u]}, ay2 = {ay[u], ay[u]};
+                    const f32x2 bg00 = f32x2{STK_UB(l0, 0), STK_UB(l0, 1)} * al2, bg01 = f32x2{STK_UB(l0, 3), STK_UB(h0, 0)} * al2;
+                    const f32x2 bg10 = f32x2{STK_UB(l1, 0), STK_UB(l1, 1)} * al2, bg11 = f32x2{STK_UB(l1, 3), STK_UB(h1, 0)} * al2;
+                    const f32x2 rl = f32x2{STK_UB(l0, 2), STK_UB(l1, 2)} * al2;       // R of the left tap, rows (iy, iy + 1)
+                    const f32x2 rr = f32x2{STK_UB(h0, 1), STK_UB(h1, 1)} * al2;       // R of the right tap
+                    const f32x2 t0 = pk_fma(ax2, bg01 - bg00, bg00), t1 = pk_fma(ax2, bg11 - bg10, bg10);
+                    const f32x2 tr = pk_fma(ax2, rr - rl, rl);                        // (row iy, row iy + 1)
+                    s01 = s01 + pk_fma(ay2, t1 - t0, t0);
+                    s2 = s2 + __builtin_fmaf(ay[u], tr.y - tr.x, tr.x);
                 }
             }
             continue;
@@ -270,12 +306,12 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
                 {
                     const float p00 = v00 ? STK_CH(tl0, 0) : b0, p01 = v01 ? STK_CH(tr0, 0) : b0;
                     const float p10 = v10 ? STK_CH(tl1, 0) : b0, p11 = v11 ? STK_CH(tr1, 0) : b0;
-                    s0 = s0 + STK_LERP(p00, p01, p10, p11);
+                    s01.x = s01.x + STK_LERP(p00, p01, p10, p11);
                 }
                 {
                     const float p00 = v00 ? STK_CH(tl0, 8) : b1, p01 = v01 ? STK_CH(tr0, 8) : b1;
                     const float p10 = v10 ? STK_CH(tl1, 8) : b1, p11 = v11 ? STK_CH(tr1, 8) : b1;
-                    s1 = s1 + STK_LERP(p00, p01, p10, p11);
+                    s01.y = s01.y + STK_LERP(p00, p01, p10, p11);
                 }
                 {
                     const float p00 = v00 ? STK_CH(tl0, 16) : b2, p01 = v01 ? STK_CH(tr0, 16) : b2;
@@ -286,15 +322,14 @@ __global__ __launch_bounds__(256) void warp_accumulate_u8c3_kernel(WarpArgs a) {
         }
     }
 #undef STK_CH
+#undef STK_UB
 #undef STK_LERP
-    accp[0] = s0; accp[1] = s1; accp[2] = s2;
+    accp[0] = s01.x; accp[1] = s01.y; accp[2] = s2;
 }
 
 // 16-bit BGR fast path (16-bit stacks: stk_hybrid_match): the two horizontally adjacent taps of a row are 12 contiguous
 // bytes -> one 12-byte load; waves whose footprints are all interior take it, border waves take per-tap conditional loads.
 // Same operation sequence as the generic kernel.
-struct Tap12 { uint32_t a, b, c; };   // B0 G0 | R0 B1 | G1 R1 (16 bits each)
-
 __device__ __forceinline__ Tap12 load_tap12(const uint8_t* p) {
     Tap12 t;
     __builtin_memcpy(&t, p, 12);
@@ -327,18 +362,23 @@ __global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) 
             f32x2 XY = pk_fma(f32x2{fr->M[0], fr->M[3]}, f32x2{fx, fx}, pk_fma(f32x2{fr->M[1], fr->M[4]}, f32x2{fy, fy}, f32x2{fr->M[2], fr->M[5]}));
             if (!AFFINE) {
                 const float W = __builtin_fmaf(fr->M[6], fx, __builtin_fmaf(fr->M[7], fy, fr->M[8]));
-                const float aw = __builtin_fabsf(W);
-                const bool safe = (__builtin_fmaxf(__builtin_fmaxf(aw, __builtin_fabsf(XY.x)), __builtin_fabsf(XY.y)) < 1.0995116e12f) &
-                                  (aw > 9.094947e-13f);
-                if (__all(safe)) XY = div2_shared(XY, W);
-                else { XY.x = XY.x / W; XY.y = XY.y / W; }
+                if (fr->flags & WARPFRAME_DIV_IN_RANGE) XY = div2_shared(XY, W);     // decided per frame on the host (uniform branch)
+                else {
+                    const float aw = __builtin_fabsf(W);
+                    const bool safe = (aw < 1.0995116e12f) & (__builtin_fabsf(XY.x) < 1.0995116e12f) & (__builtin_fabsf(XY.y) < 1.0995116e12f) &
+                                      (aw > 9.094947e-13f);                         // compares: a NaN operand fails
+                    if (__all(safe)) XY = div2_shared(XY, W);
+                    else { XY.x = XY.x / W; XY.y = XY.y / W; }
+                }
             }
             const float X = XY.x, Y = XY.y;
             const bool finite = (__builtin_fabsf(X) < 1e9f) & (__builtin_fabsf(Y) < 1e9f);
             const float flx = __builtin_floorf(X), fly = __builtin_floorf(Y);
             ix[u] = finite ? (int)flx : -100000; iy[u] = finite ? (int)fly : -100000;
             ax[u] = finite ? X - flx : 0.0f; ay[u] = finite ? Y - fly : 0.0f;
-            interior &= ((unsigned)ix[u] < (unsigned)(sw - 1)) & ((unsigned)iy[u] < (unsigned)(sh - 1));
+            // (a row to spare below, as in the u8 kernel: the aligned 16-byte window of the last pixel pair of the last row
+            // would end 4 bytes past the frame; rows sh-2 and sh-1 are left to the rim path)
+            interior &= ((unsigned)ix[u] < (unsigned)(sw - 1)) & ((unsigned)iy[u] < (unsigned)(sh - 2));
         }
 #define STK_LERP16(p00, p01, p10, p11)                                                   \
     __builtin_fmaf(ay[u], __builtin_fmaf(ax[u], (p11) - (p10), (p10)) - __builtin_fmaf(ax[u], (p01) - (p00), (p00)), \
@@ -349,18 +389,39 @@ __global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) 
             for (int u = 0; u < WU; u++) {
                 const uint8_t* src = (const uint8_t*)a.frames[min(f0 + u, a.n_frames - 1)].src;
                 const unsigned o = (unsigned)(__mul24(iy[u], stride_el) + ix[u] * 3) * 2u;
-                r0[u] = load_tap12(src + o);
-                r1[u] = load_tap12(src + o + (unsigned)stride_el * 2u);
+                const uint8_t* src1 = src + (unsigned)stride_el * 2u;               // uniform second-row base
+                if (a.frames[min(f0 + u, a.n_frames - 1)].flags & WARPFRAME_SRC_ALIGNED4) {
+                    // as in the u8 kernel: a dword-aligned 16-byte window instead of a 12-byte gather at a 6-byte lane stride
+                    // that starts on an odd word in half of the lanes; v_alignbyte shifts by 0 or 2 bytes
+                    const unsigned oa = o & ~3u, sh = o & 3u;
+                    uint32_t t0[4], t1[4];
+                    __builtin_memcpy(t0, __builtin_assume_aligned(src + oa, 4), 16);
+                    __builtin_memcpy(t1, __builtin_assume_aligned(src1 + oa, 4), 16);
+                    r0[u] = Tap12{__builtin_amdgcn_alignbyte(t0[1], t0[0], sh), __builtin_amdgcn_alignbyte(t0[2], t0[1], sh), __builtin_amdgcn_alignbyte(t0[3], t0[2], sh)};
+                    r1[u] = Tap12{__builtin_amdgcn_alignbyte(t1[1], t1[0], sh), __builtin_amdgcn_alignbyte(t1[2], t1[1], sh), __builtin_amdgcn_alignbyte(t1[3], t1[2], sh)};
+                } else {
+                    r0[u] = load_tap12(src + o);
+                    r1[u] = load_tap12(src1 + o);
+                }
             }
 #pragma unroll
             for (int u = 0; u < WU; u++) {
                 if (f0 + u < a.n_frames) {
-                    const float t00[3] = {(float)(r0[u].a & 0xffffu) * alpha, (float)(r0[u].a >> 16) * alpha, (float)(r0[u].b & 0xffffu) * alpha};
-                    const float t01[3] = {(float)(r0[u].b >> 16) * alpha, (float)(r0[u].c & 0xffffu) * alpha, (float)(r0[u].c >> 16) * alpha};
-                    const float t10[3] = {(float)(r1[u].a & 0xffffu) * alpha, (float)(r1[u].a >> 16) * alpha, (float)(r1[u].b & 0xffffu) * alpha};
-                    const float t11[3] = {(float)(r1[u].b >> 16) * alpha, (float)(r1[u].c & 0xffffu) * alpha, (float)(r1[u].c >> 16) * alpha};
-#pragma unroll
-                    for (int c = 0; c < 3; c++) s[c] = s[c] + STK_LERP16(t00[c], t01[c], t10[c], t11[c]);
+                    // same pairing as the u8 kernel: (B, G) of a tap and R of the two rows go through v_pk_mul / v_pk_fma
+                    const f32x2 al2 = {alpha, alpha}, ax2 = {ax[u], ax[u]}, ay2 = {ay[u], ay[u]};
+#define STK_LO16(d) ((float)((d) & 0xffffu))
+#define STK_HI16(d) ((float)((d) >> 16))
+                    const f32x2 bg00 = f32x2{STK_LO16(r0[u].a), STK_HI16(r0[u].a)} * al2, bg01 = f32x2{STK_HI16(r0[u].b), STK_LO16(r0[u].c)} * al2;
+                    const f32x2 bg10 = f32x2{STK_LO16(r1[u].a), STK_HI16(r1[u].a)} * al2, bg11 = f32x2{STK_HI16(r1[u].b), STK_LO16(r1[u].c)} * al2;
+                    const f32x2 rl = f32x2{STK_LO16(r0[u].b), STK_LO16(r1[u].b)} * al2;
+                    const f32x2 rr = f32x2{STK_HI16(r0[u].c), STK_HI16(r1[u].c)} * al2;
+#undef STK_LO16
+#undef STK_HI16
+                    const f32x2 t0 = pk_fma(ax2, bg01 - bg00, bg00), t1 = pk_fma(ax2, bg11 - bg10, bg10);
+                    const f32x2 tr = pk_fma(ax2, rr - rl, rl);
+                    const f32x2 vbg = pk_fma(ay2, t1 - t0, t0);
+                    s[0] = s[0] + vbg.x; s[1] = s[1] + vbg.y;
+                    s[2] = s[2] + __builtin_fmaf(ay[u], tr.y - tr.x, tr.x);
                 }
             }
             continue;

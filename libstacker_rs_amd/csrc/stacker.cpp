@@ -243,7 +243,12 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
 static stk_status ecc_prepare_reference(stk_ctx* ctx, const EccPlan& pl, const void* img, int depth, int cn,
                                         size_t stride_bytes, int gauss) {
     HIP_TRY(launch_grey_blur(img, depth, cn, pl.w, pl.h, stride_bytes, gauss, ctx->blur_tmp.as<float>(), pl.templ_row_stride, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->ref.p, 0, pl.ref_plane_floats * 5 * sizeof(float), ctx->stream));
+    // the zero border is written once per geometry: ref_planes_kernel only ever writes the interior, so a stack of the same
+    // size as the last one (every step of a shard's life) finds the border as it left it (171 MB of memset = 22 us at 4K)
+    if (ctx->ref_zeroed_ptr != ctx->ref.p || ctx->ref_zeroed_w != pl.w || ctx->ref_zeroed_h != pl.h) {
+        HIP_TRY(hipMemsetAsync(ctx->ref.p, 0, pl.ref_plane_floats * 5 * sizeof(float), ctx->stream));
+        ctx->ref_zeroed_ptr = ctx->ref.p; ctx->ref_zeroed_w = pl.w; ctx->ref_zeroed_h = pl.h;
+    }
     float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
     float* gxy = ctx->ref.as<float>() + 3 * pl.ref_plane_floats + 2 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
     HIP_TRY(launch_ref_planes(ctx->blur_tmp.as<float>(), pl.templ_row_stride, pl.w, pl.h, base, base + pl.ref_plane_floats,
@@ -377,10 +382,32 @@ static const char* ecc_status_message(int st) {
 }
 
 // fold frames into `sum` (device, tightly packed or strided) through their warps
-stk_status warp_fold(stk_ctx* ctx, const std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
+stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
                             size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
                             int is_affine, float* acc, size_t acc_stride_floats, int accumulate) {
     if (wf.empty()) return STK_OK;
+    // Per frame, once: may the fast kernels divide X / W and Y / W through one shared reciprocal chain everywhere in the
+    // destination rectangle? W, X, Y are affine in (x, y): their extremes over [0, w-1] x [0, h-1] are at the corners. The
+    // kernel's own per-pixel bounds are 2^-40 < |W| and |W|, |X|, |Y| < 2^40; the corners are tested in double against
+    // 2^-36 / 2^36, which leaves the f32 rounding of the kernel's fma chains (relative 1e-7) far inside the margin. A NaN
+    // or infinite entry fails every comparison: the flag stays clear and the kernel tests pixel by pixel.
+    for (WarpFrame& f : wf) {
+        f.flags = (((uintptr_t)f.src | (uintptr_t)src_row_bytes) & 3) == 0 ? WARPFRAME_SRC_ALIGNED4 : 0;
+        if (is_affine) continue;
+        bool ok = true;
+        double wsign = 0;
+        const double cx[2] = {0.0, (double)(w - 1)}, cy[2] = {0.0, (double)(h - 1)};
+        for (int k = 0; k < 4 && ok; k++) {
+            const double x = cx[k & 1], y = cy[k >> 1];
+            const double X = (double)f.M[0] * x + (double)f.M[1] * y + (double)f.M[2];
+            const double Y = (double)f.M[3] * x + (double)f.M[4] * y + (double)f.M[5];
+            const double W = (double)f.M[6] * x + (double)f.M[7] * y + (double)f.M[8];
+            const double lim = 68719476736.0;       // 2^36
+            ok = std::fabs(W) > 1.0 / lim && std::fabs(W) < lim && std::fabs(X) < lim && std::fabs(Y) < lim;
+            if (k == 0) wsign = W; else ok = ok && (W > 0) == (wsign > 0);       // no zero crossing of W inside the rectangle
+        }
+        if (ok) f.flags |= WARPFRAME_DIV_IN_RANGE;
+    }
     HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * wf.size()));
     HIP_TRY(hipMemcpyAsync(ctx->warpframes.p, wf.data(), sizeof(WarpFrame) * wf.size(), hipMemcpyHostToDevice, ctx->stream));
     WarpArgs a{};

@@ -167,8 +167,12 @@ def test_warp_u8_fast_path_is_bit_identical_to_the_generic_kernel(stacker, dtype
     """warp_accumulate_u8c3_kernel (and its 16-bit sibling) shares one reciprocal chain between X / W and Y / W (the compiler's own IEEE expansion
     without the range scaling) and skips clamps and border selects on interior waves: wherever all four taps are inside
     the frame it must return the very bits of the generic kernel (true `/`, per-tap selects), which BORDER_REPLICATE selects."""
+    _fast_path_vs_generic(stacker, dtype, 333, 517)             # not a multiple of the 64 x 4 tile; odd row size: 8-byte gathers
+    _fast_path_vs_generic(stacker, dtype, 333, 516)             # rows a multiple of 4 bytes: dword-aligned 12-byte windows (round 3)
+
+
+def _fast_path_vs_generic(stacker, dtype, h, w):
     rng = np.random.default_rng(3)
-    h, w = 333, 517                                             # not a multiple of the 64 x 4 tile
     top = 255 if dtype == np.uint8 else 65535
     frame = rng.integers(0, top + 1, (h, w, 3)).astype(dtype)
     ones = np.full((h, w, 3), 255, dtype)
@@ -192,3 +196,36 @@ def test_warp_u8_fast_path_is_bit_identical_to_the_generic_kernel(stacker, dtype
     acc2 = stacker.warp_accumulate(frame, mats[1], acc=acc.copy())
     accg2 = stacker.warp_accumulate(frame, mats[1], border_mode=1, acc=accg.copy())
     assert np.array_equal(acc2[inside], accg2[inside])
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_warp_fast_paths_equal_the_generic_kernel_everywhere_also_for_non_finite_maps(stacker, dtype):
+    """BORDER_CONSTANT on every pixel, rim and border included: the u8 / u16 fast kernels against the generic kernel, which
+    the same pixel values reach as a float32 frame. Also for maps with inf / NaN coordinates (a NaN X or Y with
+    a finite W once passed the fast path's range test, v_max drops NaN operands, and accumulated NaN; OpenCV's
+    saturate_cast sends such a coordinate to the border): inverse entries that overflow f32 (inf * 0 = NaN in column 0),
+    an affine map with a NaN translation, and matrices whose W range is tested per frame on the host (round 3)."""
+    for w in (203, 204):                                        # odd rows (8-byte gathers) and dword-aligned rows (12-byte windows)
+        _fast_paths_everywhere(stacker, dtype, 131, w)
+
+
+def _fast_paths_everywhere(stacker, dtype, h, w):
+    rng = np.random.default_rng(11)
+    top = 255 if dtype == np.uint8 else 65535
+    frame = rng.integers(0, top + 1, (h, w, 3)).astype(dtype)
+    as_f32 = frame.astype(np.float32)
+    from libstacker_rs_amd import synth
+    bv = (0.25, 0.5, 0.75, 0.0)
+    cases = [(np.eye(3), False), (synth.random_homography(rng, w, h, 12.0), False),
+             (np.array([[0.7, 0.2, 15.3], [-0.25, 0.9, 40.1], [4e-4, -3e-4, 1.0]]), False),
+             (np.array([[1, 0, 0], [0, 1, 0], [-0.02, 0, 1.0]]), False),                     # W changes sign inside the image
+             (np.diag([1e-39, 1.0, 1.0]), False), (np.diag([1.0, 1e-39, 1.0]), False),       # inverse entries overflow f32 -> inf, inf * 0 = NaN
+             (np.array([[1, 0, 1e30], [0, 1, 0], [0, 0, 1.0]]), False),                      # huge finite coordinates
+             (np.array([[1.0, 0.01, np.nan], [0.0, 1.0, 3.0]]), True),                       # affine, NaN translation
+             (np.array([[1.0, 0.01, 2.5], [0.02, 1.0, -3.25]]), True)]
+    for M, aff in cases:
+        for value in ((0, 0, 0, 0), bv):
+            fast = stacker.warp_accumulate(frame, M, is_affine=aff, border_value=value)
+            slow = stacker.warp_accumulate(as_f32, M, is_affine=aff, border_value=value)
+            assert np.array_equal(fast, slow, equal_nan=False), (M, value)
+            assert np.isfinite(fast).all()
