@@ -83,7 +83,7 @@ struct EccSched {
     int done[64];
     int frame_of[64];
     int live;
-    int pad[63];
+    int pad[63 + 128];
 };
 constexpr int ECC_TICKET_NEXT_BITS = 11, ECC_TICKET_UNITS_BITS = 8;
 __host__ __device__ constexpr int ecc_ticket_next(int w) { return w & ((1 << ECC_TICKET_NEXT_BITS) - 1); }
@@ -125,6 +125,10 @@ struct EccIterArgs {
     // an all-fine run is 34 % slower, and no threshold made the tail of a 32-frame shard shorter.)
     EccSched* sched;             // persistent scheduler only
 };
+#ifndef STK_PSTRIDE_MUL
+#define STK_PSTRIDE_MUL 1
+#endif
+__host__ __device__ inline int ecc_pstride(int nb) { return nb * STK_PSTRIDE_MUL; }
 
 struct WarpFrame {
     const void* src;

@@ -130,10 +130,18 @@ template <int MOTION> struct EccUnitLds {
 // `unit` in [0, a.nb): the region. The slot's state (frame, warp, centring offsets) is read with agent-scope loads: under the persistent scheduler another
 // workgroup wrote it a moment ago, without a kernel boundary in between.
 template <int MOTION>
-__device__ __forceinline__ void ecc_col_unit(const EccIterArgs& a, const int slot, const int unit, EccUnitLds<MOTION>& lds) {
+__device__ __forceinline__ void ecc_col_unit(const EccIterArgs& a, const int slot, const int unit, EccUnitLds<MOTION>& lds
+#ifdef STK_UNIT_CUT
+    , const int cut
+#endif
+) {
     constexpr bool HOMOGRAPHY = MOTION == STK_MOTION_HOMOGRAPHY;
     constexpr int P = MotionTraits<MOTION>::P, NH = P * (P + 1) / 2, NS = NH + 3 * P + 6;
+#ifdef STK_UNIT_CUT
+    const int region = cut == 1 ? unit : unit / cut;
+#else
     const int region = unit;
+#endif
     const EccSlot* sl = a.slots + slot;
     SlotConst c;
     const int frame = load_slot_const_coherent(sl, a, c);
@@ -176,7 +184,16 @@ __device__ __forceinline__ void ecc_col_unit(const EccIterArgs& a, const int slo
     // this wave's run of (column, row) units, column-major
     const int g = region * 4 + wave;
     int u = g * a.units_q + min(g, a.units_r);
+#ifdef STK_UNIT_CUT
+    int uend = u + a.units_q + (g < a.units_r ? 1 : 0);
+    if (cut > 1) {
+        const int len = uend - u, sub = unit - region * cut;
+        uend = u + (len * (sub + 1)) / cut;
+        u = u + (len * sub) / cut;
+    }
+#else
     const int uend = u + a.units_q + (g < a.units_r ? 1 : 0);
+#endif
     bool no_ring = false;                     // set for one pass of the loop: the strip failed the ring's run-time check
     while (u < uend) {
         const int u_strip = u;
@@ -572,7 +589,7 @@ __device__ __forceinline__ void ecc_col_unit(const EccIterArgs& a, const int slo
         const double s = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
         // [slot][sum][unit]; write-through, agent scope: whoever solves this iteration — the next kernel, or under the
         // persistent scheduler the workgroup that completes it, on any XCD — reads these with agent-scope loads
-        __hip_atomic_store(&a.partials[((size_t)slot * NS + k) * a.nb + unit], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partials[((size_t)slot * NS + k) * ecc_pstride(a.nb) + unit], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its partials have left before anyone signals for them
 }

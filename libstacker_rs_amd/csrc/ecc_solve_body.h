@@ -47,7 +47,16 @@ __device__ inline int slot_take_next(EccSlot* sl, EccQueue* queue, const float* 
 // Persistent scheduler: publish the units of the iteration slot `slot` runs next (frame >= 0, `iter` iterations done), or
 // retire the slot. Called by ONE lane after it has stored the slot's state; the stores must have left before the ticket
 // words open the iteration, and `done` must be clear before the first unit can arrive.
-__device__ inline void ecc_sched_arm(const EccIterArgs& a, int slot, int frame, int iter) {
+// what the solve needs of the launch's arguments (by value: the persistent kernel calls it out of line)
+struct EccSolveArgs {
+    double* partials;
+    EccSlot* slots;
+    EccSched* sched;
+    int nb;
+};
+__device__ __forceinline__ EccSolveArgs ecc_solve_args(const EccIterArgs& a) { return EccSolveArgs{a.partials, a.slots, a.sched, a.nb}; }
+
+__device__ inline void ecc_sched_arm(const EccSolveArgs& a, int slot, int frame, int iter) {
     EccSched* sc = a.sched;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (frame < 0) {
@@ -99,7 +108,7 @@ struct EccSolveLds {
 // normal equations and the loop control, hands the slot its next iteration or its next frame. Every thread of the
 // workgroup calls it and returns from it. Under the persistent scheduler (a.sched) it also arms the slot's next units.
 template <int SOLVE_WAVES>
-__device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, int motion, EccCriteria crit, EccQueue* queue,
+__device__ __forceinline__ void ecc_solve_body(const EccSolveArgs a, int slot, int motion, EccCriteria crit, EccQueue* queue,
                                                EccFrameResult* results, const float* init_warps, EccSolveLds& L) {
     EccSlot* sl = a.slots + slot;
     const int frame = ld_agent(&sl->frame);
@@ -123,7 +132,7 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
 #pragma unroll
     for (int k = 0; k < 9; k++) wm[k] = ld_agent(&sl->warp[k]);
     const int n_units = a.nb;
-    const double* base = a.partials + (size_t)slot * NS * a.nb;
+    const double* base = a.partials + (size_t)slot * NS * ecc_pstride(a.nb);
     {
         constexpr int KR = (ECC_MAX_SUMS + SOLVE_WAVES - 1) / SOLVE_WAVES;     // sums per wave
         constexpr int KB = KR < 6 ? KR : 6;                                     // sums per batch (bounds the registers)
@@ -141,7 +150,7 @@ __device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, i
 #pragma unroll
                     for (int r = 0; r < KB; r++) {
                         const int k = wave + SOLVE_WAVES * (r0 + r);
-                        v[r][j] = (b < n_units && k < NS) ? ld_agent(&base[(size_t)k * a.nb + b]) : 0.0;
+                        v[r][j] = (b < n_units && k < NS) ? ld_agent(&base[(size_t)k * ecc_pstride(a.nb) + b]) : 0.0;
                     }
                 }
 #pragma unroll

@@ -15,7 +15,11 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
     const EccSlot* sl = a.slots + slot;
     if (sl->frame < 0) return;
     __shared__ EccUnitLds<MOTION> lds;
+#ifdef STK_UNIT_CUT
+    ecc_col_unit<MOTION>(a, slot, region, lds, 1);
+#else
     ecc_col_unit<MOTION>(a, slot, region, lds);
+#endif
 }
 
 void ecc_set_col_units(EccIterArgs& a) {

@@ -43,6 +43,15 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 
 struct EccTicket { int slot, unit; };       // slot < 0: nothing left anywhere, leave
 
+// The solve, OUT OF LINE: inlined into the persistent kernel it shares the unit's register allocation (128 VGPRs, all
+// taken by the pixel loops) and its serial tail runs on spilled values — 90 us per solve instead of 20, which a lone
+// frame's iteration pays in full (152 us against 63 + 20 for a launch per iteration). As a call it gets registers of its own.
+template <int MOTION>
+__device__ __attribute__((noinline)) void ecc_solve_call(EccSolveArgs a, int slot, EccCriteria crit, EccQueue* queue,
+                                                         EccFrameResult* results, const float* init_warps, EccSolveLds* L) {
+    ecc_solve_body<4>(a, slot, MOTION, crit, queue, results, init_warps, *L);
+}
+
 // Wave 0 draws the next ticket. `look`: the ticket words of the workgroup's own class, lane = slot, already loaded by the
 // caller (so that the load shares a round trip with the arrival of the previous ticket), or -1 to load them here.
 // Policy (variants measured on 32- and 128-frame 4K stacks, round 3: all within 1 % of each other except the phase, which
@@ -84,6 +93,10 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_persist_kernel(EccIterArg
     __shared__ EccPersistLds<MOTION> lds;
     __shared__ EccTicket sh_tk;
     __shared__ int sh_last;
+#ifdef STK_UNIT_CUT
+    __shared__ int sh_cut;
+    if (threadIdx.x == 0) sh_cut = a.n_slots > 100 ? 4 : 1;
+#endif
     const int cls = (int)blockIdx.x & 7, rot = ((int)blockIdx.x >> 3) % a.n_slots;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
@@ -94,7 +107,22 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_persist_kernel(EccIterArg
     for (;;) {
         const EccTicket tk = sh_tk;
         if (tk.slot < 0) return;                             // uniform: every wave of the workgroup leaves here
+#ifdef STK_UNIT_CUT
+        ecc_col_unit<MOTION>(a, tk.slot, tk.unit, lds.unit, max(1, min(4, sh_cut)));
+#else
+#ifdef STK_PERSIST_TIMING
+        const long long t_unit0 = wall_clock64();
+#endif
         ecc_col_unit<MOTION>(a, tk.slot, tk.unit, lds.unit); // ends with every storing wave's s_waitcnt vmcnt(0)
+#ifdef STK_PERSIST_TIMING
+        const long long t_unit1 = wall_clock64();
+        if (blockIdx.x == 264 && threadIdx.x == 0) {        // one ordinary workgroup's first units: start and end
+            long long* dbg2 = reinterpret_cast<long long*>(a.sched->pad) + 32;
+            const int k = a.sched->pad[61];
+            if (k < 24) { dbg2[2 * k] = t_unit0; dbg2[2 * k + 1] = t_unit1; a.sched->pad[190 - k] = tk.unit; a.sched->pad[61] = k + 1; }
+        }
+#endif
+#endif
         __syncthreads();                                     // all partials of this unit have left the workgroup
         if (wave == 0) {
             // arrive for this unit and look for the next one at the same time: the two round trips overlap
@@ -112,11 +140,22 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_persist_kernel(EccIterArg
         if (sh_last) {
             // this unit completed the slot's iteration: every unit's partials were stored and signalled before our
             // arrival returned; they are read with agent-scope loads only
-            ecc_solve_body<4>(a, tk.slot, MOTION, crit, queue, results, init_warps, lds.solve);
+#ifdef STK_PERSIST_TIMING
+            long long* dbg = reinterpret_cast<long long*>(a.sched->pad);
+            const int it = a.sched->pad[62];
+            if (threadIdx.x == 0 && it < 6) { dbg[it * 5 + 0] = t_unit0; dbg[it * 5 + 1] = t_unit1; dbg[it * 5 + 2] = wall_clock64(); }
+#endif
+            ecc_solve_call<MOTION>(ecc_solve_args(a), tk.slot, crit, queue, results, init_warps, &lds.solve);
+#ifdef STK_PERSIST_TIMING
+            if (threadIdx.x == 0 && it < 6) dbg[it * 5 + 3] = wall_clock64();
+#endif
             if (wave == 0) {                                 // (the lane that armed the next iteration is in this wave)
                 const EccTicket nt = ecc_acquire(a, cls, rot, -1);
                 if (threadIdx.x == 0) sh_tk = nt;
             }
+#ifdef STK_PERSIST_TIMING
+            if (threadIdx.x == 0 && it < 6) { dbg[it * 5 + 4] = wall_clock64(); a.sched->pad[62] = it + 1; }
+#endif
             __syncthreads();
         }
     }

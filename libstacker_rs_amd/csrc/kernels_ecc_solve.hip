@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void ecc_solve_kernel(EccIterArgs a, int motio
         return;
     }
     __shared__ EccSolveLds L;
-    ecc_solve_body<4>(a, slot, motion, crit, queue, results, init_warps, L);
+    ecc_solve_body<4>(ecc_solve_args(a), slot, motion, crit, queue, results, init_warps, L);
 }
 
 hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue,
@@ -62,7 +62,7 @@ __global__ void ecc_init_kernel(EccSlot* slots, int n_slots, EccQueue* queue, in
     if (threadIdx.x == 0) {
         queue->next_frame = min(avail, n_slots); queue->n_frames = n_frames; queue->frames_done = 0; queue->ring_fallbacks = 0;
         queue->ready = ready0 < 0 ? n_frames : ready0;
-        if (sched) sched->live = min(avail, n_slots);
+        if (sched) { sched->live = min(avail, n_slots); for (int k = 0; k < 63 + 128; k++) sched->pad[k] = 0; }
     }
 }
 

@@ -160,6 +160,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ecc_ring") ctx->opt_ecc_ring = value != 0;
     else if (n == "ecc_ring_lookahead") { if (value < 1 || value > 5) return fail(ctx, STK_INVALID_PARAMS, "ecc_ring_lookahead must be 1..5"); ctx->opt_ecc_ring_lookahead = (int)value; }
     else if (n == "ecc_persist") { if (value < 0 || value > 2) return fail(ctx, STK_INVALID_PARAMS, "ecc_persist must be 0, 1 or 2"); ctx->opt_ecc_persist = (int)value; }
+    else if (n == "ecc_persist_wgs") ctx->opt_ecc_persist_wgs = (int)value;
     else if (n == "ecc_variant") { if (value != 0 && value != 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 3 (production) or 0 (direct cross-check)"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
@@ -238,7 +239,7 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     HIP_TRY(ctx->slots.reserve(sizeof(EccSlot) * pl.n_slots));
     HIP_TRY(ctx->queue.reserve(256 + sizeof(EccSched)));        // EccQueue, then the persistent scheduler's words on lines of their own
     HIP_TRY(ctx->results.reserve(sizeof(EccFrameResult) * std::max(n_templates, 1)));
-    HIP_TRY(ctx->partials.reserve(sizeof(double) * pl.n_slots * (size_t)pl.nb * pl.nsums));   // [slot][sum][nb]
+    HIP_TRY(ctx->partials.reserve(sizeof(double) * pl.n_slots * (size_t)ecc_pstride(pl.nb) * pl.nsums));   // [slot][sum][nb]
     return STK_OK;
 }
 
@@ -316,7 +317,8 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, q, pl.n_templates, r, init_warps_dev, ctx->stream, feed ? 0 : -1, a.sched, pl.nb));
     if (persist && crit.n_iter >= 1) {
         // four workgroups per CU stay resident (the unit's registers and LDS allow exactly that); no more than there are units
-        const int wgs = std::max(8, std::min(4 * ctx->n_cus, std::min(1024, pl.n_slots * pl.nb)));
+        int wgs = std::max(8, std::min(4 * ctx->n_cus, std::min(1024, pl.n_slots * pl.nb)));
+        if (ctx->opt_ecc_persist_wgs > 0) wgs = std::max(8, std::min(1024, ctx->opt_ecc_persist_wgs));
         const bool timed = ctx->opt_profile >= 2;
         if (timed && ctx->prof_ev.empty()) {
             ctx->prof_ev.resize(8192);
@@ -330,6 +332,17 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
         HIP_TRY(hipMemcpyAsync(&ctx->host_done[2], &q->ring_fallbacks, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipMemcpyAsync(&ctx->host_done[0], &q->frames_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+#ifdef STK_PERSIST_TIMING
+        { EccSched hs; (void)hipMemcpy(&hs, a.sched, sizeof(hs), hipMemcpyDeviceToHost);
+          const long long* d = reinterpret_cast<const long long*>(hs.pad);
+          for (int it = 0; it < std::min(6, hs.pad[62]); it++)
+              fprintf(stderr, "PERSIST_DBG it %d: unit %.1f us, arrive %.1f, solve %.1f, acquire %.1f; since prev solve end %.1f\n", it, (d[it*5+1]-d[it*5+0])/100.0,
+                      (d[it*5+2]-d[it*5+1])/100.0, (d[it*5+3]-d[it*5+2])/100.0, (d[it*5+4]-d[it*5+3])/100.0, it ? (d[it*5+0]-d[(it-1)*5+3])/100.0 : 0.0);
+          const long long* d2 = d + 32;
+          for (int k = 0; k < std::min(24, hs.pad[61]); k++)
+              fprintf(stderr, "PERSIST_DBG wg264 unit %d (region %d): run %.1f us, gap before %.1f us\n", k, hs.pad[190 - k], (d2[2*k+1]-d2[2*k])/100.0, k ? (d2[2*k]-d2[2*k-1])/100.0 : 0.0);
+          (void)hipMemset(a.sched->pad, 0, sizeof(hs.pad)); }
+#endif
         if (ctx->host_done[0] != pl.n_templates) return fail(ctx, STK_PROCESSING_ERROR, "ECC scheduler left frames behind (internal error)");
         ctx->timing.ecc_ring_fallbacks += ctx->host_done[2];
         if (timed) { ctx->timing.ecc_iter_ms += ev_ms(ctx->prof_ev[0], ctx->prof_ev[1]); ctx->timing.ecc_iter_timed += 1; }

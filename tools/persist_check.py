@@ -10,6 +10,11 @@ sizes = [(320, 240, 5), (640, 480, 9), (1000, 700, 3), (1920, 1080, 17), (3840, 
 if len(sys.argv) > 1:
     sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 st = Stacker(0)
+if os.environ.get("TORCH_STREAM"):
+    st.use_torch_stream()
+REPS = int(os.environ.get("REPS", "3"))
+if os.environ.get("WGS"):
+    st.set_option("ecc_persist_wgs", int(os.environ["WGS"]))
 for motion in (MotionType.Homography, MotionType.Affine):
     p = EccMatchParameters(motion, 5000, 1e-5, 5)
     for (w, h, n) in sizes:
@@ -23,7 +28,7 @@ for motion in (MotionType.Homography, MotionType.Affine):
             out, stats = st.ecc_match(dev, p, return_stats=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            reps = 3
+            reps = REPS
             for _ in range(reps):
                 out2 = st.ecc_match(dev, p)
             torch.cuda.synchronize()
