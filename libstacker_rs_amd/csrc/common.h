@@ -66,34 +66,6 @@ struct EccQueue {
 #endif
 };
 
-// Scheduling state of the persistent ECC kernel (kernels_ecc_persist.hip): the work of a slot's current iteration is
-// n_units workgroup-sized units (a fixed image region each: the summation partition does not depend on who runs a unit);
-// every resident workgroup draws tickets, runs units, and the workgroup whose unit completes an iteration solves it
-// and arms the next one. No kernel boundary, no host round trip, no barrier between iterations or between frames.
-//   W[c][s]   ticket word of slot s for the units of region class c (region % 8 == c: the class shares an XCD's L2 when
-//             the workgroups are dealt round-robin, speed only): (iterations done + 1) << 19 | units of this class << 11 |
-//             next unit. A ticket (= one unit) is valid iff its `next` field is below its `units` field — the word
-//             carries the bound of its own iteration, so a late draw on a finished iteration can never be mistaken for a
-//             ticket of the next.
-//   done[s]   units of slot s's current iteration that have been worked off; the arrival that completes it solves the slot
-//   frame_of[s]  frame in the slot (INT_MAX: idle) — workgroups prefer the oldest frame that has units left
-//   live      slots holding a frame; 0: every workgroup leaves
-struct EccSched {
-    int W[8][64];
-    int done[64];
-    int frame_of[64];
-    int live;
-    int pad[63 + 128];
-};
-constexpr int ECC_TICKET_NEXT_BITS = 11, ECC_TICKET_UNITS_BITS = 8;
-__host__ __device__ constexpr int ecc_ticket_next(int w) { return w & ((1 << ECC_TICKET_NEXT_BITS) - 1); }
-__host__ __device__ constexpr int ecc_ticket_units(int w) { return (w >> ECC_TICKET_NEXT_BITS) & ((1 << ECC_TICKET_UNITS_BITS) - 1); }
-__host__ __device__ constexpr int ecc_ticket_gen(int w) { return (int)((unsigned)w >> (ECC_TICKET_NEXT_BITS + ECC_TICKET_UNITS_BITS)); }
-// gen: iterations done + 1, modulo 8192 — it only orders the slots for the scheduler, nothing depends on its value
-__host__ __device__ constexpr int ecc_ticket_word(int gen, int tickets) {
-    return (int)((((unsigned)gen & 0x1fffu) << (ECC_TICKET_NEXT_BITS + ECC_TICKET_UNITS_BITS)) | ((unsigned)tickets << ECC_TICKET_NEXT_BITS));
-}
-
 struct EccCriteria {
     int    n_iter;      // COUNT ? max_count : 200
     double eps;         // EPS ? epsilon : -1
@@ -113,22 +85,14 @@ struct EccIterArgs {
     int n_slots;                 // slots iterated by this launch: slot0 .. slot0 + n_slots - 1
     int nb;                      // blocks per slot (multiple of 8)
     double* partials;            // [all slots][nsums][nb]
+    double* sums;                // [all slots][ECC_MAX_SUMS]: the reduced sums, stage 1 -> stage 2 of the solve kernel
+    int* tickets;                // [all slots]: arrival counter of the solve kernel's stage-1 workgroups (self-resetting)
     int slot0;                   // first slot of this launch (0: all slots in one launch)
     int ring;                    // column-walking pass: 1 = frame-0 rows through the per-wave LDS ring where a strip allows it (option ecc_ring)
     int ring_lookahead;          // frame-0 rows the ring keeps ahead of the row being fetched: 5; lower only to provoke the fallback (option ecc_ring_lookahead)
     int* ring_fallbacks;         // device counter: strips whose ring bounds failed the run-time check and were redone by the gather loop (EccQueue::ring_fallbacks)
     int units_q, units_r;        // column-walking pass: (column strip, row) units per wave and the remainder (set by launch_ecc_iter)
-    // Work units: an iteration of a frame is nb units, one per region (a fixed share of the frame's pixels: the summation
-    // partition depends on the frame size only). partials: [slot][sum][nb].
-    // (Measured and dropped, round 3: cutting late iterations into four times as many units, so that the last frames of a
-    // shard spread over more workgroups — a 28-row strip pays the LDS ring's start-up and the 66-sum lane fold too often,
-    // an all-fine run is 34 % slower, and no threshold made the tail of a 32-frame shard shorter.)
-    EccSched* sched;             // persistent scheduler only
 };
-#ifndef STK_PSTRIDE_MUL
-#define STK_PSTRIDE_MUL 1
-#endif
-__host__ __device__ inline int ecc_pstride(int nb) { return nb * STK_PSTRIDE_MUL; }
 
 struct WarpFrame {
     const void* src;
@@ -183,13 +147,8 @@ hipError_t launch_ecc_solve(const EccIterArgs& a, int motion, EccCriteria crit, 
                             EccFrameResult* results, hipStream_t s, const float* init_warps = nullptr);
 hipError_t launch_sharpness(const void* grey, int depth, int w, int h, int metric, int ksize, void* partials, int n_blocks,
                             hipStream_t s);
-hipError_t launch_ecc_init(EccSlot* slots, int n_slots, EccQueue* queue, int n_frames, EccFrameResult* results,
-                           const float* init_warps /* n_frames*9 or null */, hipStream_t s, int ready0 = -1 /* -1: all */,
-                           EccSched* sched = nullptr, int nb = 0);
-// the whole alignment of every frame that is ready, in ONE launch (kernels_ecc_persist.hip); a.units_q / units_r set like launch_ecc_iter_col
-hipError_t launch_ecc_persist(const EccIterArgs& a, int motion, EccCriteria crit, EccQueue* queue, EccFrameResult* results,
-                              const float* init_warps, int n_workgroups, hipStream_t s);
-void ecc_set_col_units(EccIterArgs& a);
+hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* queue, int n_frames, EccFrameResult* results,
+                           const float* init_warps /* n_frames*9 or null */, hipStream_t s, int ready0 = -1 /* -1: all */);
 hipError_t launch_ecc_set_ready(EccQueue* queue, int ready, hipStream_t s);
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s);
 hipError_t launch_scale(const float* in, float* out, size_t n, float scale, hipStream_t s);

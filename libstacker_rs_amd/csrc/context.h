@@ -59,9 +59,6 @@ struct stk_ctx {
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
     int opt_ecc_ring = 1;         // column-walking ECC pass: frame-0 rows through the per-wave LDS ring (0: always gather from global memory)
     int opt_ecc_ring_lookahead = 5;   // debug: frame-0 rows the ring keeps ahead (5 = production; less makes the run-time check fire and the strip fall back)
-    int opt_ecc_persist = 1;      // device-resident stacks: 1 = one persistent, self-scheduling ECC launch where it pays (ecc_wants_persist), 0 = never, 2 = wherever possible
-    int opt_ecc_persist_wgs = 0;  // workgroups of the persistent ECC launch (0 = 4 per CU)
-    int n_cus = 256;
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = production (column-walking homography pass / pipelined affine family), 0 = direct cross-check
     stk_timing timing{};
     hipEvent_t ev[8] = {};

@@ -2,7 +2,6 @@
 // constants. Included by kernels_ecc.hip and kernels_ecc_col.hip.
 #pragma once
 #include "common.h"
-#include <cstddef>
 
 namespace stk {
 
@@ -65,23 +64,6 @@ __device__ __forceinline__ void load_slot_const(const EccSlot* sl, const EccIter
     c.iw = a.ref.w; c.ih = a.ref.h;
     c.fiw = (float)a.ref.w; c.fih = (float)a.ref.h;
     c.mxw = (float)(a.ref.w - 1); c.mxh = (float)(a.ref.h - 1);
-}
-
-// The same constants through agent-scope loads (they bypass the per-CU caches, which no other workgroup's stores refresh):
-// lane k fetches word k of the slot — frame, iter, warp[9], cI, cT — and the values go to scalar registers by readlane.
-// Returns the slot's frame.
-__device__ __forceinline__ int load_slot_const_coherent(const EccSlot* sl, const EccIterArgs& a, SlotConst& c) {
-    static_assert(offsetof(EccSlot, warp) == 8 && offsetof(EccSlot, cI) == 44 && offsetof(EccSlot, cT) == 48, "EccSlot layout");
-    const int lane = threadIdx.x & 63;
-    const int w = __hip_atomic_load(reinterpret_cast<const int*>(sl) + (lane < 13 ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    auto f = [&](int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(w, k)); };
-    c.m0 = f(2); c.m1 = f(3); c.m2 = f(4); c.m3 = f(5); c.m4 = f(6); c.m5 = f(7); c.m6 = f(8); c.m7 = f(9); c.m8 = f(10);
-    c.cI = f(11); c.cT = f(12);
-    c.den_is_w = (c.m8 == 1.0f);
-    c.iw = a.ref.w; c.ih = a.ref.h;
-    c.fiw = (float)a.ref.w; c.fih = (float)a.ref.h;
-    c.mxw = (float)(a.ref.w - 1); c.mxh = (float)(a.ref.h - 1);
-    return __builtin_amdgcn_readlane(w, 0);
 }
 
 }  // namespace stk

@@ -13,17 +13,10 @@
 
 namespace stk {
 
-// Slot state is handed from workgroup to workgroup (the solve of iteration k writes what the units of iteration k+1 and
-// the next solve read) — under the persistent scheduler without a kernel boundary in between, from any XCD. Every access
-// to it is therefore an agent-scope relaxed atomic: write-through stores, loads that bypass the per-CU caches
-// (MI355X_MICROARCH.md, inter-workgroup visibility); the ordering comes from the ticket / arrival counters.
-template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // Claim the next template for a free slot, if one has been prepared already (queue->ready is raised by the prep stream
 // while later frames are still crossing PCIe; device-resident stacks start with ready == n_frames). A slot that finds
-// nothing stays idle (frame = -1) and asks again at the next solve launch. Returns the frame taken, or -1.
-__device__ inline int slot_take_next(EccSlot* sl, EccQueue* queue, const float* init_warps) {
+// nothing stays idle (frame = -1) and asks again at the next solve launch.
+__device__ inline void slot_take_next(EccSlot* sl, EccQueue* queue, const float* init_warps) {
     const int avail = min(__hip_atomic_load(&queue->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), queue->n_frames);
     int nxt = __hip_atomic_load(&queue->next_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool got = false;
@@ -33,44 +26,14 @@ __device__ inline int slot_take_next(EccSlot* sl, EccQueue* queue, const float* 
         nxt = seen;
     }
     if (got) {
-        st_agent(&sl->frame, nxt);
-        st_agent(&sl->iter, 0);
-        for (int k = 0; k < 9; k++) st_agent(&sl->warp[k], init_warps ? init_warps[(size_t)nxt * 9 + k] : ((k % 4 == 0) ? 1.f : 0.f));
-        st_agent(&sl->cI, 0.f); st_agent(&sl->cT, 0.f);
-        st_agent(&sl->rho, -1.0);
-        return nxt;
+        sl->frame = nxt;
+        sl->iter = 0;
+        for (int k = 0; k < 9; k++) sl->warp[k] = init_warps ? init_warps[(size_t)nxt * 9 + k] : ((k % 4 == 0) ? 1.f : 0.f);
+        sl->cI = 0; sl->cT = 0;
+        sl->rho = -1;
+    } else {
+        sl->frame = -1;
     }
-    st_agent(&sl->frame, -1);
-    return -1;
-}
-
-// Persistent scheduler: publish the units of the iteration slot `slot` runs next (frame >= 0, `iter` iterations done), or
-// retire the slot. Called by ONE lane after it has stored the slot's state; the stores must have left before the ticket
-// words open the iteration, and `done` must be clear before the first unit can arrive.
-// what the solve needs of the launch's arguments (by value: the persistent kernel calls it out of line)
-struct EccSolveArgs {
-    double* partials;
-    EccSlot* slots;
-    EccSched* sched;
-    int nb;
-};
-__device__ __forceinline__ EccSolveArgs ecc_solve_args(const EccIterArgs& a) { return EccSolveArgs{a.partials, a.slots, a.sched, a.nb}; }
-
-__device__ inline void ecc_sched_arm(const EccSolveArgs& a, int slot, int frame, int iter) {
-    EccSched* sc = a.sched;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (frame < 0) {
-        st_agent(&sc->frame_of[slot], 0x7fffffff);
-        for (int c = 0; c < 8; c++) st_agent(&sc->W[c][slot], 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        atomicSub(&sc->live, 1);
-        return;
-    }
-    const int gen = iter + 1;                                           // the scheduler's notion of the slot's progress (ecc_acquire)
-    st_agent(&sc->frame_of[slot], frame);
-    st_agent(&sc->done[slot], 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int c = 0; c < 8; c++) st_agent(&sc->W[c][slot], ecc_ticket_word(gen, a.nb / 8));
 }
 
 // cv::invert(DECOMP_LU) closed forms for CV_32F 2x2 / 3x3 (evaluated in double), serial.
@@ -96,53 +59,47 @@ __device__ inline void invert_small_f32(const float* S, int n, float* D) {
     } else { for (int i = 0; i < 9; i++) D[i] = 0; }
 }
 
-struct EccSolveLds {
-    double S[ECC_MAX_SUMS];
-    float AB[8][16];          // [A | B] of the LU inverse, B starts as I
-    float Hinv[64];
-    float vec[4][8];          // ipf, tpf, iph, epf
-    double dvec[2][8];        // ipd, tpd
-};
-
-// One workgroup of SOLVE_WAVES wavefronts solves one slot: reduces the iteration's unit partials (fixed order), runs the
-// normal equations and the loop control, hands the slot its next iteration or its next frame. Every thread of the
-// workgroup calls it and returns from it. Under the persistent scheduler (a.sched) it also arms the slot's next units.
-template <int SOLVE_WAVES>
-__device__ __forceinline__ void ecc_solve_body(const EccSolveArgs a, int slot, int motion, EccCriteria crit, EccQueue* queue,
-                                               EccFrameResult* results, const float* init_warps, EccSolveLds& L) {
+// One workgroup of SOLVE_WAVES wavefronts solves one slot. PRE_REDUCED: the block partials were already reduced to
+// the 66 sums by the caller's stage 1 (kernels_ecc_solve.hip); otherwise this workgroup reduces them itself.
+template <int SOLVE_WAVES, bool PRE_REDUCED = false>
+__device__ __forceinline__ void ecc_solve_body(const EccIterArgs& a, int slot, int motion, EccCriteria crit, EccQueue* queue,
+                                               EccFrameResult* results, const float* init_warps) {
     EccSlot* sl = a.slots + slot;
-    const int frame = ld_agent(&sl->frame);
+    const int frame = sl->frame;
     if (frame < 0) return;
     const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
     const int NH = P * (P + 1) / 2, NS = NH + 3 * P + 6;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double (&S)[ECC_MAX_SUMS] = L.S;
-    float (&AB)[8][16] = L.AB;
-    float (&Hinv)[64] = L.Hinv;
-    float (&vec)[4][8] = L.vec;
-    double (&dvec)[2][8] = L.dvec;
 
-    // ---- 1. reduce the unit partials: wave w owns sums w, w + SOLVE_WAVES, ...; lane l adds units l, l + 64, ... in
-    //         ascending order, then a fixed shuffle tree. Several loads are issued before the first add so the round
-    //         trips overlap; the order of the additions does not depend on the batching ---------------------------------
-    // slot state needed at the very end: loaded now so the latency hides behind the reduction
-    const double prev_rho = ld_agent(&sl->rho);
-    const int prev_iter = ld_agent(&sl->iter);
+    __shared__ double S[ECC_MAX_SUMS];
+    __shared__ float AB[8][16];          // [A | B] of the LU inverse, B starts as I
+    __shared__ float Hinv[64];
+    __shared__ float vec[4][8];          // ipf, tpf, iph, epf
+    __shared__ double dvec[2][8];        // ipd, tpd
+
+    // ---- 1. reduce block partials: 16 waves, wave w owns sums w, w+16, ...; all loads of a wave are
+    //         issued before the first add so the HBM round trips overlap --------------------------------
+    // slot state needed at the very end: loaded now (uniform -> scalar loads) so the latency hides behind the reduction
+    const double prev_rho = sl->rho;
+    const int prev_iter = sl->iter;
     float wm[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) wm[k] = ld_agent(&sl->warp[k]);
-    const int n_units = a.nb;
-    const double* base = a.partials + (size_t)slot * NS * ecc_pstride(a.nb);
-    {
+    for (int k = 0; k < 9; k++) wm[k] = sl->warp[k];
+    const double* base = a.partials + (size_t)slot * NS * a.nb;
+    if constexpr (PRE_REDUCED) {
+        if (tid < NS) S[tid] = a.sums[(size_t)slot * ECC_MAX_SUMS + tid];      // stage 1 ran in the caller (kernels_ecc_solve.hip)
+    } else {
         constexpr int KR = (ECC_MAX_SUMS + SOLVE_WAVES - 1) / SOLVE_WAVES;     // sums per wave
         constexpr int KB = KR < 6 ? KR : 6;                                     // sums per batch (bounds the registers)
         constexpr int JB = 5;                                                    // partials per lane and sum in flight
-        const int nbi = (n_units + 63) >> 6;
+        const int nbi = (a.nb + 63) >> 6;
         for (int r0 = 0; r0 < KR; r0 += KB) {
             double acc[KB];
 #pragma unroll
             for (int r = 0; r < KB; r++) acc[r] = 0;
             for (int j0 = 0; j0 < nbi; j0 += JB) {
+                // all KB x JB loads of the batch are issued before the first add (one memory round trip instead of
+                // JB); the adds keep the ascending-block order, out-of-range entries add +0
                 double v[KB][JB];
 #pragma unroll
                 for (int j = 0; j < JB; j++) {
@@ -150,7 +107,7 @@ __device__ __forceinline__ void ecc_solve_body(const EccSolveArgs a, int slot, i
 #pragma unroll
                     for (int r = 0; r < KB; r++) {
                         const int k = wave + SOLVE_WAVES * (r0 + r);
-                        v[r][j] = (b < n_units && k < NS) ? ld_agent(&base[(size_t)k * ecc_pstride(a.nb) + b]) : 0.0;
+                        v[r][j] = (b < a.nb && k < NS) ? base[(size_t)k * a.nb + b] : 0.0;
                     }
                 }
 #pragma unroll
@@ -172,7 +129,7 @@ __device__ __forceinline__ void ecc_solve_body(const EccSolveArgs a, int slot, i
     STK_TICK(4);
 
     // ---- 2. statistics (every thread computes the same scalars; no divergence) ------------------
-    const double cI = ld_agent(&sl->cI), cT = ld_agent(&sl->cT);
+    const double cI = sl->cI, cT = sl->cT;
     const double* ST = S + NH + 3 * P;
     const double n = ST[0];
     const double mu = n > 0 ? ST[1] / n : 0, mv = n > 0 ? ST[3] / n : 0;   // means of the centred samples
@@ -290,7 +247,7 @@ __device__ __forceinline__ void ecc_solve_body(const EccSolveArgs a, int slot, i
         vec[2][tid] = sacc;
     }
     __syncthreads();
-    if (tid != 0) return;                                     // (every other thread is done: the caller's next barrier collects them)
+    if (tid != 0) return;
     STK_TICK(7);
 
     const double last_rho = prev_rho;
@@ -337,28 +294,24 @@ __device__ __forceinline__ void ecc_solve_body(const EccSolveArgs a, int slot, i
                 m[1] = -m[3];
             }
 #pragma unroll
-            for (int k = 0; k < 9; k++) st_agent(&sl->warp[k], wm[k]);
+            for (int k = 0; k < 9; k++) sl->warp[k] = wm[k];
         }
     }
     // for (i = 1; i <= nIter && fabs(rho - last_rho) >= eps; i++): would iteration iter+1 run?
     if (!finished) finished = (iter + 1 > crit.n_iter) || !(fabs(rho - last_rho) >= crit.eps);
-    st_agent(&sl->iter, iter);
-    st_agent(&sl->last_rho, last_rho);
-    st_agent(&sl->rho, rho);
-    st_agent(&sl->cI, imgMeanF); st_agent(&sl->cT, tmpMeanF);
+    sl->iter = iter;
+    sl->last_rho = last_rho;
+    sl->rho = rho;
+    sl->cI = imgMeanF; sl->cT = tmpMeanF;
     STK_TICK(8);
-    int next_frame = frame, next_iter = iter;
     if (finished) {
         EccFrameResult* r = results + frame;
         for (int k = 0; k < 9; k++) r->warp[k] = wm[k];
         r->iters = iter; r->status = status; r->rho = rho;
-        next_frame = slot_take_next(sl, queue, init_warps);
-        next_iter = 0;
-        if (next_frame >= 0) st_agent(&sl->last_rho, 0.0);
+        slot_take_next(sl, queue, init_warps);
         __threadfence();
         atomicAdd(&queue->frames_done, 1);
     }
-    if (a.sched) ecc_sched_arm(a, slot, next_frame, next_iter);
 }
 
 

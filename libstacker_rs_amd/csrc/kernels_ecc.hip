@@ -144,7 +144,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NS], const EccIt
     if (threadIdx.x < NS) {
         const int k = threadIdx.x;
         const double s = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
-        a.partials[((size_t)slot * NS + k) * ecc_pstride(a.nb) + region] = s;   // [slot][sum][unit]
+        a.partials[((size_t)slot * NS + k) * a.nb + region] = s;   // [slot][sum][block]
     }
 }
 

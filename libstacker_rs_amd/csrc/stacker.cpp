@@ -87,8 +87,6 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     if (hipHostMalloc((void**)&ctx->host_done, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->n_cus = cus;
     ctx->kp = keypoint_workspace_create();
     ctx->hg = geom::hg_workspace_create();
     *out = ctx;
@@ -159,8 +157,6 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
     else if (n == "ecc_ring") ctx->opt_ecc_ring = value != 0;
     else if (n == "ecc_ring_lookahead") { if (value < 1 || value > 5) return fail(ctx, STK_INVALID_PARAMS, "ecc_ring_lookahead must be 1..5"); ctx->opt_ecc_ring_lookahead = (int)value; }
-    else if (n == "ecc_persist") { if (value < 0 || value > 2) return fail(ctx, STK_INVALID_PARAMS, "ecc_persist must be 0, 1 or 2"); ctx->opt_ecc_persist = (int)value; }
-    else if (n == "ecc_persist_wgs") ctx->opt_ecc_persist_wgs = (int)value;
     else if (n == "ecc_variant") { if (value != 0 && value != 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 3 (production) or 0 (direct cross-check)"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
@@ -237,9 +233,9 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     HIP_TRY(ctx->blur_tmp.reserve(pl.templ_plane_stride * sizeof(float)));
     HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1) + 1024));
     HIP_TRY(ctx->slots.reserve(sizeof(EccSlot) * pl.n_slots));
-    HIP_TRY(ctx->queue.reserve(256 + sizeof(EccSched)));        // EccQueue, then the persistent scheduler's words on lines of their own
+    HIP_TRY(ctx->queue.reserve(sizeof(EccQueue)));
     HIP_TRY(ctx->results.reserve(sizeof(EccFrameResult) * std::max(n_templates, 1)));
-    HIP_TRY(ctx->partials.reserve(sizeof(double) * pl.n_slots * (size_t)ecc_pstride(pl.nb) * pl.nsums));   // [slot][sum][nb]
+    HIP_TRY(ctx->partials.reserve(sizeof(double) * pl.n_slots * ((size_t)pl.nb * pl.nsums + ECC_MAX_SUMS) + sizeof(int) * pl.n_slots));
     return STK_OK;
 }
 
@@ -258,21 +254,6 @@ static stk_status ecc_prepare_reference(stk_ctx* ctx, const EccPlan& pl, const v
     HIP_TRY(launch_ref_planes(ctx->blur_tmp.as<float>(), pl.templ_row_stride, pl.w, pl.h, base, base + pl.ref_plane_floats,
                               base + 2 * pl.ref_plane_floats, gxy, pl.ref_stride, ctx->stream));
     return STK_OK;
-}
-
-// Which form of the alignment a device-resident stack takes (measured on MI355X, round 3):
-//   * one persistent, self-scheduling launch (kernels_ecc_persist.hip) where its per-ticket cost (two atomics, three
-//     workgroup barriers, a write-through of the partial sums: ~5 us) is small against a unit of work and where the
-//     launch-per-iteration form has nothing to fill its gaps with: frames of >= 16 000 pixels per unit (4K: 28 800) in
-//     stacks of at most 2 x slots frames — the per-GPU shard of a multi-GPU run. 32 x 4K: 8.9 -> 8.2 ms.
-//   * a launch per iteration for small frames (1080p units are 7 900 pixels: the ticket cost shows, +3 %) and for long
-//     stacks, whose template preparation runs on a second stream in the gaps between those launches (ramp-down, solve):
-//     the persistent kernel leaves no gaps, would have to prepare all templates first, and that costs what it gains.
-// ecc_persist: 1 = this rule (default), 0 = never, 2 = wherever it can run (tests).
-static bool ecc_wants_persist(const stk_ctx* ctx, const EccPlan& pl) {
-    if (ctx->opt_ecc_variant != 3 || ctx->opt_ecc_persist == 0) return false;
-    if (ctx->opt_ecc_persist >= 2) return true;
-    return (double)pl.w * pl.h / pl.nb >= 16000.0 && pl.n_templates <= 2 * pl.n_slots;
 }
 
 // run the device-side iteration queue to completion; results copied to `res`
@@ -301,54 +282,13 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     a.ring = ctx->opt_ecc_ring;
     a.ring_lookahead = ctx->opt_ecc_ring_lookahead;
     a.partials = ctx->partials.as<double>();
-    if (ctx->opt_ecc_variant == 3) {
-        if ((long long)((pl.w + 63) >> 6) * pl.h > 0x3fffffffLL) return fail(ctx, STK_INVALID_PARAMS, "frame too large");
-        ecc_set_col_units(a);
-    }
+    a.sums = a.partials + (size_t)pl.n_slots * pl.nb * pl.nsums;
+    a.tickets = reinterpret_cast<int*>(a.sums + (size_t)pl.n_slots * ECC_MAX_SUMS);
     EccQueue* q = ctx->queue.as<EccQueue>();
     EccFrameResult* r = ctx->results.as<EccFrameResult>();
     a.ring_fallbacks = &q->ring_fallbacks;
     a.slot0 = 0;
-    // Frames that are all there already (device-resident stacks; stk_find_transform_ecc): ONE persistent launch aligns them
-    // all (kernels_ecc_persist.hip). Host-fed stacks, whose frames arrive while the queue runs, take a launch per iteration.
-    const bool persist = !feed && ecc_wants_persist(ctx, pl) && pl.n_slots <= 64 && pl.nb % 8 == 0 &&
-                         pl.nb / 8 < (1 << ECC_TICKET_UNITS_BITS);
-    a.sched = persist ? reinterpret_cast<EccSched*>(ctx->queue.as<char>() + 256) : nullptr;
-    HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, q, pl.n_templates, r, init_warps_dev, ctx->stream, feed ? 0 : -1, a.sched, pl.nb));
-    if (persist && crit.n_iter >= 1) {
-        // four workgroups per CU stay resident (the unit's registers and LDS allow exactly that); no more than there are units
-        int wgs = std::max(8, std::min(4 * ctx->n_cus, std::min(1024, pl.n_slots * pl.nb)));
-        if (ctx->opt_ecc_persist_wgs > 0) wgs = std::max(8, std::min(1024, ctx->opt_ecc_persist_wgs));
-        const bool timed = ctx->opt_profile >= 2;
-        if (timed && ctx->prof_ev.empty()) {
-            ctx->prof_ev.resize(8192);
-            for (auto& e : ctx->prof_ev) HIP_TRY(hipEventCreate(&e));
-        }
-        if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[0], ctx->stream));
-        HIP_TRY(launch_ecc_persist(a, pl.motion, crit, q, r, init_warps_dev, wgs, ctx->stream));
-        if (timed) HIP_TRY(hipEventRecord(ctx->prof_ev[1], ctx->stream));
-        ctx->timing.ecc_iter_launches += 1;
-        HIP_TRY(hipMemcpyAsync(res.data(), r, sizeof(EccFrameResult) * pl.n_templates, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(&ctx->host_done[2], &q->ring_fallbacks, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(&ctx->host_done[0], &q->frames_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-#ifdef STK_PERSIST_TIMING
-        { EccSched hs; (void)hipMemcpy(&hs, a.sched, sizeof(hs), hipMemcpyDeviceToHost);
-          const long long* d = reinterpret_cast<const long long*>(hs.pad);
-          for (int it = 0; it < std::min(6, hs.pad[62]); it++)
-              fprintf(stderr, "PERSIST_DBG it %d: unit %.1f us, arrive %.1f, solve %.1f, acquire %.1f; since prev solve end %.1f\n", it, (d[it*5+1]-d[it*5+0])/100.0,
-                      (d[it*5+2]-d[it*5+1])/100.0, (d[it*5+3]-d[it*5+2])/100.0, (d[it*5+4]-d[it*5+3])/100.0, it ? (d[it*5+0]-d[(it-1)*5+3])/100.0 : 0.0);
-          const long long* d2 = d + 32;
-          for (int k = 0; k < std::min(24, hs.pad[61]); k++)
-              fprintf(stderr, "PERSIST_DBG wg264 unit %d (region %d): run %.1f us, gap before %.1f us\n", k, hs.pad[190 - k], (d2[2*k+1]-d2[2*k])/100.0, k ? (d2[2*k]-d2[2*k-1])/100.0 : 0.0);
-          (void)hipMemset(a.sched->pad, 0, sizeof(hs.pad)); }
-#endif
-        if (ctx->host_done[0] != pl.n_templates) return fail(ctx, STK_PROCESSING_ERROR, "ECC scheduler left frames behind (internal error)");
-        ctx->timing.ecc_ring_fallbacks += ctx->host_done[2];
-        if (timed) { ctx->timing.ecc_iter_ms += ev_ms(ctx->prof_ev[0], ctx->prof_ev[1]); ctx->timing.ecc_iter_timed += 1; }
-        for (auto& e : res) ctx->timing.ecc_slot_iterations += e.iters;
-        return STK_OK;
-    }
+    HIP_TRY(launch_ecc_init(a.slots, pl.n_slots, a.tickets, q, pl.n_templates, r, init_warps_dev, ctx->stream, feed ? 0 : -1));
     int fed = feed ? 0 : pl.n_templates;
     if (feed) {
         // the prep stream may raise `ready` only after the queue exists
@@ -594,9 +534,7 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     if ((st = prepare_reference(ctx->stream))) return bail(st);
     // (with `overlap_prep` the templates are prepared while the first frames already iterate: prep_ms is then the
     // reference's share only and the templates' time is inside align_ms)
-    // (device-resident stacks are aligned by ONE persistent launch over templates that all exist beforehand; the overlapped
-    // preparation below serves the launch-per-iteration form only, i.e. option ecc_persist = 0)
-    const bool overlap_prep = !ecc_wants_persist(ctx, pl) && !host_fed && !scaled && ctx->opt_prep_overlap && n - 1 > 2 * pl.n_slots;
+    const bool overlap_prep = !host_fed && !scaled && ctx->opt_prep_overlap && n - 1 > 2 * pl.n_slots;
     if (!host_fed && !overlap_prep && (st = prepare_templates(1, n - 1, ctx->stream))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     const float* seeds_dev = nullptr;

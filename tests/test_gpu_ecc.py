@@ -182,72 +182,6 @@ def test_lds_ring_path_other_motions(stacker, motion):
     assert np.array_equal(ring.cpu().numpy(), gather.cpu().numpy())
 
 
-@pytest.mark.parametrize("w,h,n,motion", [(320, 240, 5, MotionType.Homography), (1000, 700, 9, MotionType.Homography),
-                                          (1920, 1080, 17, MotionType.Homography), (3840, 2160, 9, MotionType.Homography),
-                                          (640, 480, 6, MotionType.Affine), (640, 480, 6, MotionType.Euclidean),
-                                          (640, 480, 6, MotionType.Translation)])
-def test_persistent_scheduler_equals_a_launch_per_iteration(stacker, w, h, n, motion):
-    """Device-resident shards are aligned by ONE persistent launch whose workgroups draw tickets for work units, solve the
-    iteration their unit completes and hand the slot its next iteration or frame (kernels_ecc_persist.hip); host-fed and long
-    stacks take a launch per iteration. Both run the same units over the same summation partition and reduce them in the same
-    order: iteration counts, warps and the stacked image must agree in every bit, run after run (which workgroup runs or
-    solves what differs from run to run). ecc_persist = 2 forces the persistent form also where the default rule would not
-    choose it (small frames, long stacks)."""
-    frames, _ = synth.make_stack(n, w, h, device="cuda")
-    p = EccMatchParameters(motion, 5000, 1e-5, 5)
-    res = {}
-    try:
-        for mode in (2, 0, 2):
-            stacker.set_option("ecc_persist", mode)
-            out, stats = stacker.ecc_match(frames, p, return_stats=True)
-            assert stacker.timing()["ecc_iter_launches"] == (1 if mode else stacker.timing()["ecc_iter_launches"])
-            cur = (out.cpu().numpy(), [s["iterations"] for s in stats], np.stack([s["warp"] for s in stats]))
-            if mode in res:                                   # the persistent form twice: scheduling order must not matter
-                assert cur[1] == res[mode][1] and np.array_equal(cur[2], res[mode][2]) and np.array_equal(cur[0], res[mode][0])
-            res[mode] = cur
-    finally:
-        stacker.set_option("ecc_persist", 1)
-    assert res[2][1] == res[0][1]
-    assert np.array_equal(res[2][2], res[0][2])
-    assert np.array_equal(res[2][0], res[0][0])
-
-
-def test_persistent_scheduler_queue_refill_fixed_counts_and_failures(stacker):
-    frames, _ = synth.make_stack(23, 640, 480, device="cuda")
-    try:
-        # more frames than slots: finished slots take the next frame of the queue inside the kernel
-        stacker.set_option("ecc_slots", 4)
-        outs = []
-        for mode in (2, 0):
-            stacker.set_option("ecc_persist", mode)
-            out, stats = stacker.ecc_match(frames, PARAMS, return_stats=True)
-            outs.append((out.cpu().numpy(), [s["iterations"] for s in stats], np.stack([s["warp"] for s in stats])))
-        assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][0], outs[1][0])
-        stacker.set_option("ecc_slots", 0)
-        # fixed iteration counts (no eps)
-        for mc in (7, 1):
-            p = EccMatchParameters(MotionType.Homography, mc, None, 5)
-            res = []
-            for mode in (2, 0):
-                stacker.set_option("ecc_persist", mode)
-                out, stats = stacker.ecc_match(frames[:6], p, return_stats=True)
-                assert all(s["iterations"] == mc for s in stats[1:])
-                res.append((out.cpu().numpy(), np.stack([s["warp"] for s in stats])))
-            assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-        # a frame ECC cannot correlate fails the whole call (the reference's `?`), by both forms, and the context survives
-        bad = frames[:5].clone()
-        bad[3] = 77
-        for mode in (2, 0):
-            stacker.set_option("ecc_persist", mode)
-            with pytest.raises(OpenCvError):
-                stacker.ecc_match(bad, PARAMS)
-            ok = stacker.ecc_match(frames[:5], PARAMS)
-            assert torch.isfinite(ok).all()
-    finally:
-        stacker.set_option("ecc_slots", 0)
-        stacker.set_option("ecc_persist", 1)
-
-
 def test_lds_ring_run_time_check_falls_back_to_the_gather_loop(stacker):
     """The ring's safety rests on bounds derived from a strip's corners plus a scalar check, row by row, that what a fetch
     reads has landed and has not been overwritten. A strip that fails the check is redone by the gather loop (its

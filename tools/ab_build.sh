@@ -7,7 +7,7 @@ name=$1; src=$2; shift 2
 base=$(basename "$src")
 orig=${ORIG:-$base}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result -I. -I../../include"
-case "$orig" in kernels_ecc_col.hip|kernels_ecc_persist.hip) FLAGS="$FLAGS -fno-slp-vectorize";; esac
+case "$orig" in kernels_ecc_col.hip) FLAGS="$FLAGS -fno-slp-vectorize";; esac
 mkdir -p ../ab /tmp/ab
 /opt/rocm/bin/hipcc $FLAGS "$@" -c -o /tmp/ab/$name.o "$src" 2>/dev/null
 objs=$(ls build/*.o | grep -v "build/$orig.o")
