@@ -243,12 +243,13 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
                                   int32_t* n_added, stk_frame_stats* stats);
 
 /* ---- file front-end ---------------------------------------------------------
- * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit), 8-bit
- * RGB / grey PNG and stripped 8/16-bit grey / RGB TIFF (the latter two when libpng16.so.16 / libtiff.so.5 can be loaded
- * at run time): BGR or grey rows, tightly packed, into `data`
- * (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.
- * Other formats (JPEG, tiled TIFF, PNG with alpha / 16 bit / palette ...) -> STK_NOT_IMPLEMENTED; unreadable / not an image ->
- * STK_BACKEND_ERROR, as the reference's empty Mat + cvtColor does. */
+ * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit), grey / YCbCr
+ * JPEG (libjpeg-turbo's libjpeg.so.8, OpenCV's decoder family at its default settings), 8- and 16-bit grey / RGB PNG
+ * (libpng16.so.16) and stripped 8/16-bit grey / RGB TIFF (libtiff.so.5 / .6), the libraries loaded at run time: BGR or
+ * grey rows, tightly packed, into `data` (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.
+ * PNG with an alpha channel decodes to 4 or 2 channels under IMREAD_UNCHANGED and the reference's cvtColor(BGR2GRAY)
+ * rejects that: STK_BACKEND_ERROR, like a file that is unreadable or not an image (the reference's empty Mat + cvtColor).
+ * Other flavours (CMYK JPEG, tiled TIFF, palette PNG, BMP / WebP / EXR ...) -> STK_NOT_IMPLEMENTED. */
 stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width,
                       int32_t* height, int32_t* channels, int32_t* depth);
 /* keypoint_match / ecc_match in the reference's own call shape: a list of file paths, first = reference frame

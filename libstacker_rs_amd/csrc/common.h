@@ -106,6 +106,57 @@ constexpr int WARPFRAME_DIV_IN_RANGE = 1;
 // the frame's base address and its row stride are multiples of 4: the u8 fast path may gather dword-aligned 12-byte windows
 constexpr int WARPFRAME_SRC_ALIGNED4 = 2;
 
+// 3x3 inverse by the adjugate in double (cv::invert on a 3x3 CV_64F) and invertAffineTransform: what warpPerspective /
+// warpAffine do to the forward matrix before they map destination pixels (lib.rs:290-299, 780-803). Host and device run
+// the same operations (no contraction: -ffp-contract=off), so a warp frame built on either side has the same bits.
+__host__ __device__ inline void warp_invert3x3(const double* m, double* o) {
+    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (d == 0.0) { for (int i = 0; i < 9; i++) o[i] = 0; return; }
+    d = 1.0 / d;
+    double t[9] = {(m[4] * m[8] - m[5] * m[7]) * d, (m[2] * m[7] - m[1] * m[8]) * d, (m[1] * m[5] - m[2] * m[4]) * d,
+                   (m[5] * m[6] - m[3] * m[8]) * d, (m[0] * m[8] - m[2] * m[6]) * d, (m[2] * m[3] - m[0] * m[5]) * d,
+                   (m[3] * m[7] - m[4] * m[6]) * d, (m[1] * m[6] - m[0] * m[7]) * d, (m[0] * m[4] - m[1] * m[3]) * d};
+    for (int i = 0; i < 9; i++) o[i] = t[i];
+}
+__host__ __device__ inline void warp_invert_affine(const double* m, double* o) {
+    double D = m[0] * m[4] - m[1] * m[3];
+    D = D != 0 ? 1.0 / D : 0;
+    const double A11 = m[4] * D, A22 = m[0] * D, A12 = -m[1] * D, A21 = -m[3] * D;
+    o[0] = A11; o[1] = A12; o[2] = -A11 * m[2] - A12 * m[5];
+    o[3] = A21; o[4] = A22; o[5] = -A21 * m[2] - A22 * m[5];
+    o[6] = 0; o[7] = 0; o[8] = 1;
+}
+// WARPFRAME_* flags of a frame for a w x h destination. Range flag: W, X, Y are affine in (x, y), so their extremes over
+// [0, w-1] x [0, h-1] sit at the corners; the kernels' own per-pixel bounds are 2^-40 < |W| and |W|, |X|, |Y| < 2^40; the
+// corners are tested in double against 2^-36 / 2^36, which leaves the f32 rounding of the kernels' fma chains (relative
+// 1e-7) far inside the margin. A NaN or infinite entry fails every comparison: the flag stays clear and the kernel tests
+// pixel by pixel.
+__host__ __device__ inline int warp_frame_flags(const void* src, const float* M, size_t src_row_bytes, int w, int h, int is_affine) {
+    int flags = (((unsigned long long)(size_t)src | (unsigned long long)src_row_bytes) & 3) == 0 ? WARPFRAME_SRC_ALIGNED4 : 0;
+    if (is_affine) return flags;
+    bool ok = true;
+    double wsign = 0;
+    const double cx[2] = {0.0, (double)(w - 1)}, cy[2] = {0.0, (double)(h - 1)};
+    for (int k = 0; k < 4 && ok; k++) {
+        const double x = cx[k & 1], y = cy[k >> 1];
+        const double X = (double)M[0] * x + (double)M[1] * y + (double)M[2];
+        const double Y = (double)M[3] * x + (double)M[4] * y + (double)M[5];
+        const double W = (double)M[6] * x + (double)M[7] * y + (double)M[8];
+        const double lim = 68719476736.0;       // 2^36
+        const double aW = W < 0 ? -W : W, aX = X < 0 ? -X : X, aY = Y < 0 ? -Y : Y;
+        ok = aW > 1.0 / lim && aW < lim && aX < lim && aY < lim;
+        if (k == 0) wsign = W; else ok = ok && (W > 0) == (wsign > 0);       // no zero crossing of W inside the rectangle
+    }
+    return ok ? flags | WARPFRAME_DIV_IN_RANGE : flags;
+}
+__host__ __device__ inline void warp_frame_make(WarpFrame& wf, const void* src, const double* M, int is_affine) {
+    double inv[9];
+    if (is_affine) warp_invert_affine(M, inv); else warp_invert3x3(M, inv);
+    wf.src = src;
+    wf.flags = 0;
+    for (int k = 0; k < 9; k++) { wf.Md[k] = inv[k]; wf.M[k] = (float)inv[k]; }
+}
+
 struct WarpArgs {
     const WarpFrame* frames;
     int n_frames;
@@ -151,6 +202,11 @@ hipError_t launch_ecc_init(EccSlot* slots, int n_slots, int* tickets, EccQueue* 
                            const float* init_warps /* n_frames*9 or null */, hipStream_t s, int ready0 = -1 /* -1: all */);
 hipError_t launch_ecc_set_ready(EccQueue* queue, int ready, hipStream_t s);
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s);
+// the fold's frame table straight from the ECC results, on the device: entry 0 = the reference frame under the identity
+// (if add_reference), then template k under results[k].warp — what the host loop of ecc_shard_impl builds, bit for bit
+hipError_t launch_warp_frames_from_ecc(const EccFrameResult* results, const void* const* src_ptrs /* n_templates + 1, device */,
+                                       int n_templates, int add_reference, int is_affine, int w, int h, size_t src_row_bytes,
+                                       WarpFrame* out, hipStream_t s);
 hipError_t launch_scale(const float* in, float* out, size_t n, float scale, hipStream_t s);
 hipError_t launch_add(float* acc, const float* in, size_t n, hipStream_t s);
 

@@ -68,7 +68,7 @@ struct stk_ctx {
     int ref_zeroed_w = 0, ref_zeroed_h = 0;
     std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
     // workspace
-    DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps;
+    DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps, frameptrs;
     stk::KeypointWorkspace* kp = nullptr;
     stk::geom::HgWorkspace* hg = nullptr;   // findHomography batch workspace (homography.cpp)
     stk::HostPool* host_pool = nullptr;
@@ -97,6 +97,9 @@ stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr);
 stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
                      size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
                      int is_affine, float* acc, size_t acc_stride_floats, int accumulate);
+stk_status warp_fold_enqueue(stk_ctx* ctx, int n_frames, int depth, int w, int h, int cn, size_t src_row_bytes, double alpha,
+                             int border_mode, const double* border_value, int is_affine, float* acc, size_t acc_stride_floats,
+                             int accumulate);
 void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine);
 stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c);
 size_t image_stride_floats(const stk_image_f32* im);

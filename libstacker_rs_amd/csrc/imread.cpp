@@ -93,18 +93,29 @@ void pnm_decode(const unsigned char* raster, const Pnm& p, void* dst) {
     }
 }
 
-// ---- PNG through libpng 1.6's simplified API, resolved at run time ------------------------------------------
-struct PngImage {            // png_image of png.h (libpng 1.6, PNG_IMAGE_VERSION 1)
-    void* opaque;
-    uint32_t version, width, height, format, flags, colormap_entries, warning_or_error;
-    char message[64];
-};
-constexpr uint32_t PNG_FMT_GRAY = 0x00, PNG_FMT_RGB = 0x02, PNG_FMT_BGR = 0x12;   // COLOR = 0x02, BGR = 0x10
-
+// ---- PNG through libpng 1.6's row API, resolved at run time (opaque handles only: no struct layouts involved) ----------
+// What OpenCV's PngDecoder does for IMREAD_UNCHANGED (grfmt_png.cpp) [OCV-RECALL]: samples as stored — 8 bit, or 16 bit
+// byte-swapped to native order, never gamma-converted (which is why libpng's simplified API, whose 16-bit output is "linear
+// light", is not used) —, palette expanded to RGB, 1/2/4-bit grey expanded to 8, colour delivered as BGR.
 struct PngApi {
-    int (*begin_read_from_file)(PngImage*, const char*) = nullptr;
-    int (*finish_read)(PngImage*, const void* background, void* buffer, int32_t row_stride, void* colormap) = nullptr;
-    void (*image_free)(PngImage*) = nullptr;
+    const char* (*get_libpng_ver)(const void*) = nullptr;
+    void* (*create_read_struct)(const char*, void*, void (*)(void*, const char*), void (*)(void*, const char*)) = nullptr;
+    void* (*create_info_struct)(void*) = nullptr;
+    void (*destroy_read_struct)(void**, void**, void**) = nullptr;
+    jmp_buf* (*set_longjmp_fn)(void*, void (*)(jmp_buf, int), size_t) = nullptr;
+    void (*longjmp_)(void*, int) = nullptr;
+    void (*init_io)(void*, FILE*) = nullptr;
+    void (*read_info)(void*, void*) = nullptr;
+    uint32_t (*get_IHDR)(void*, void*, uint32_t*, uint32_t*, int*, int*, int*, int*, int*) = nullptr;
+    uint32_t (*get_valid)(void*, void*, uint32_t) = nullptr;
+    void (*set_palette_to_rgb)(void*) = nullptr;
+    void (*set_expand_gray_1_2_4_to_8)(void*) = nullptr;
+    void (*set_swap)(void*) = nullptr;
+    void (*set_bgr)(void*) = nullptr;
+    int (*set_interlace_handling)(void*) = nullptr;
+    void (*read_update_info)(void*, void*) = nullptr;
+    size_t (*get_rowbytes)(void*, void*) = nullptr;
+    void (*read_row)(void*, unsigned char*, unsigned char*) = nullptr;
     bool ok = false;
 };
 
@@ -113,29 +124,89 @@ const PngApi& png_api() {
         PngApi a;
         void* h = dlopen("libpng16.so.16", RTLD_NOW | RTLD_LOCAL);
         if (!h) return a;
-        a.begin_read_from_file = reinterpret_cast<int (*)(PngImage*, const char*)>(dlsym(h, "png_image_begin_read_from_file"));
-        a.finish_read = reinterpret_cast<int (*)(PngImage*, const void*, void*, int32_t, void*)>(dlsym(h, "png_image_finish_read"));
-        a.image_free = reinterpret_cast<void (*)(PngImage*)>(dlsym(h, "png_image_free"));
-        a.ok = a.begin_read_from_file && a.finish_read && a.image_free;
+#define STK_PNG_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name))
+        STK_PNG_SYM(get_libpng_ver, "png_get_libpng_ver"); STK_PNG_SYM(create_read_struct, "png_create_read_struct");
+        STK_PNG_SYM(create_info_struct, "png_create_info_struct"); STK_PNG_SYM(destroy_read_struct, "png_destroy_read_struct");
+        STK_PNG_SYM(set_longjmp_fn, "png_set_longjmp_fn"); STK_PNG_SYM(longjmp_, "png_longjmp"); STK_PNG_SYM(init_io, "png_init_io");
+        STK_PNG_SYM(read_info, "png_read_info"); STK_PNG_SYM(get_IHDR, "png_get_IHDR"); STK_PNG_SYM(get_valid, "png_get_valid");
+        STK_PNG_SYM(set_palette_to_rgb, "png_set_palette_to_rgb"); STK_PNG_SYM(set_expand_gray_1_2_4_to_8, "png_set_expand_gray_1_2_4_to_8");
+        STK_PNG_SYM(set_swap, "png_set_swap"); STK_PNG_SYM(set_bgr, "png_set_bgr"); STK_PNG_SYM(set_interlace_handling, "png_set_interlace_handling");
+        STK_PNG_SYM(read_update_info, "png_read_update_info"); STK_PNG_SYM(get_rowbytes, "png_get_rowbytes"); STK_PNG_SYM(read_row, "png_read_row");
+#undef STK_PNG_SYM
+        a.ok = a.get_libpng_ver && a.create_read_struct && a.create_info_struct && a.destroy_read_struct && a.set_longjmp_fn && a.longjmp_ &&
+               a.init_io && a.read_info && a.get_IHDR && a.get_valid && a.set_palette_to_rgb && a.set_expand_gray_1_2_4_to_8 && a.set_swap &&
+               a.set_bgr && a.set_interlace_handling && a.read_update_info && a.get_rowbytes && a.read_row;
         return a;
     }();
     return api;
 }
 
-// 0 decoded into pix (BGR or grey, 8 bit); 1 not decodable (read error); 2 a PNG flavour this build does not take
+static void png_quiet_warning(void*, const char*) {}
+static void png_trap_error(void* png, const char*) { png_api().longjmp_(png, 1); }   // must not return
+
+// One pass over the file. pix == nullptr: geometry only (w, h, cn, depth out). Else the decoded rows go to pix, which holds
+// w * h * cn * depth / 8 bytes. libpng reports errors by longjmp into this frame: it owns no object with a destructor and
+// touches nothing but PODs, the FILE* and the caller's buffer (the reason for the two passes: the buffer exists beforehand).
+// 0 ok; 1 not decodable; 2 a flavour this build does not take (alpha: the reference would stack four channels).
+static int png_decode_raw(const PngApi& api, const char* path, int* w, int* h, int* cn, int* depth, unsigned char* pix) noexcept {
+    FILE* volatile f = std::fopen(path, "rb");
+    if (!f) return 1;
+    void* volatile png = api.create_read_struct(api.get_libpng_ver(nullptr), nullptr, png_trap_error, png_quiet_warning);
+    if (!png) { std::fclose(f); return 2; }
+    void* volatile info = api.create_info_struct(png);
+    if (!info) { void* p0 = png; api.destroy_read_struct(&p0, nullptr, nullptr); std::fclose(f); return 2; }
+    jmp_buf* jb = api.set_longjmp_fn(png, longjmp, sizeof(jmp_buf));
+    if (!jb || setjmp(*jb)) {
+        void* p0 = png; void* i0 = info;
+        api.destroy_read_struct(&p0, &i0, nullptr);
+        std::fclose(f);
+        return 1;
+    }
+    api.init_io(png, f);
+    api.read_info(png, info);
+    uint32_t iw = 0, ih = 0;
+    int bits = 0, color = 0, interlace = 0, comp = 0, filter = 0;
+    api.get_IHDR(png, info, &iw, &ih, &bits, &color, &interlace, &comp, &filter);
+    int rc = 0;
+    const bool has_alpha = (color & 4) != 0 || api.get_valid(png, info, 0x10u /* PNG_INFO_tRNS */) != 0;
+    if (iw == 0 || ih == 0 || iw > 65500 || ih > 65500) rc = 1;
+    else if (has_alpha) rc = 2;
+    else {
+        *w = (int)iw; *h = (int)ih;
+        *cn = (color & 2) ? 3 : 1;                           // PNG_COLOR_MASK_COLOR (palette images carry it too)
+        *depth = bits == 16 ? 16 : 8;
+        if (pix) {
+            if (color == 3) api.set_palette_to_rgb(png);     // PNG_COLOR_TYPE_PALETTE
+            if (color == 0 && bits < 8) api.set_expand_gray_1_2_4_to_8(png);
+            if (bits == 16) api.set_swap(png);               // big-endian file order -> native (x86-64)
+            if (*cn == 3) api.set_bgr(png);
+            const int passes = api.set_interlace_handling(png);
+            api.read_update_info(png, info);
+            const size_t row = (size_t)iw * *cn * (*depth / 8);
+            if (api.get_rowbytes(png, info) != row) rc = 2;
+            else
+                for (volatile int pass = 0; pass < passes; pass = pass + 1)
+                    for (volatile uint32_t y = 0; y < ih; y = y + 1) api.read_row(png, pix + row * y, nullptr);
+        }
+    }
+    void* p0 = png; void* i0 = info;
+    api.destroy_read_struct(&p0, &i0, nullptr);
+    std::fclose(f);
+    return rc;
+}
+
+// 0 decoded into pix (BGR or grey, 8 or 16 bit); 1 not decodable (read error); 2 a PNG flavour this build does not take
 int png_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
     const PngApi& api = png_api();
     if (!api.ok) return 2;
-    PngImage im;
-    std::memset(&im, 0, sizeof im);
-    im.version = 1;
-    if (!api.begin_read_from_file(&im, path)) { api.image_free(&im); return 1; }
-    if (im.format != PNG_FMT_RGB && im.format != PNG_FMT_GRAY) { api.image_free(&im); return 2; }   // alpha / 16-bit / palette
-    p.w = (int)im.width; p.h = (int)im.height; p.cn = im.format == PNG_FMT_RGB ? 3 : 1; p.depth = 8; p.data_ofs = 0;
-    if (im.format == PNG_FMT_RGB) im.format = PNG_FMT_BGR;      // imread returns BGR
-    pix.resize((size_t)p.w * p.h * p.cn);
-    if (!api.finish_read(&im, nullptr, pix.data(), 0, nullptr)) { api.image_free(&im); return 1; }
-    return 0;                                                     // finish_read frees the image on success
+    int w = 0, h = 0, cn = 0, depth = 0;
+    int rc = png_decode_raw(api, path, &w, &h, &cn, &depth, nullptr);
+    if (rc) return rc;
+    pix.resize((size_t)w * h * cn * (depth / 8));
+    rc = png_decode_raw(api, path, &w, &h, &cn, &depth, pix.data());
+    if (rc) return rc;
+    p.w = w; p.h = h; p.cn = cn; p.depth = depth; p.data_ofs = 0;
+    return 0;
 }
 
 // ---- TIFF through libtiff's handle-based API, resolved at run time (no struct layouts involved) --------------------
@@ -313,6 +384,62 @@ bool jpeg_sof(const unsigned char* b, size_t n, unsigned& w, unsigned& h, int& c
     return false;
 }
 
+// The libjpeg calls proper. longjmp lands back in this frame, so it owns nothing with a destructor and changes no
+// automatic object after setjmp except through `volatile` PODs and caller-provided raw buffers (ISO C++ [support.runtime]:
+// anything else would be indeterminate after the jump): `store` holds the decompress object (capacity >= 4096 + 256),
+// `pix` the sw * shh * scomp output bytes, `line` one row. 0 decoded; 1 not decodable; 2 not taken by this build.
+static int jpeg_decode_raw(const JpegApi& api, const unsigned char* file, size_t file_size, unsigned sw, unsigned shh, int scomp,
+                           unsigned char* store, size_t store_cap, unsigned char* pix, unsigned char* line, int* struct_size_io) noexcept {
+    JpegErrorMgr err;
+    JpegTrap trap;
+    JpegDecompressHead* const c = reinterpret_cast<JpegDecompressHead*>(store);
+    volatile bool created = false;
+    volatile int attempts = 0;
+    volatile int struct_size = *struct_size_io;
+    if (setjmp(trap.jb)) {
+        // JERR_BAD_STRUCT_SIZE is the only error that can arrive before the object exists: msg_parm.i[0] = expected size
+        if (!created && attempts < 2 && trap.parm0 > (int)sizeof(JpegDecompressHead) && (size_t)trap.parm0 + 256 <= store_cap &&
+            trap.parm0 != struct_size) {
+            struct_size = trap.parm0;                       // and once more from the top, through the same setjmp
+        } else {
+            if (created) api.destroy(c);
+            return created ? 1 : 2;
+        }
+    }
+    if (!created) {
+        std::memset(store, 0, store_cap);
+        std::memset(&err, 0, sizeof err);
+        c->err = api.std_error(&err);
+        err.error_exit = jpeg_trap_exit; err.output_message = jpeg_quiet; err.emit_message = jpeg_quiet_emit;
+        c->client_data = &trap;
+        attempts = attempts + 1;
+        api.create(c, 80, (size_t)struct_size);             // may longjmp with the size the library expects
+        c->client_data = &trap;                             // jpeg_CreateDecompress zeroes the struct but keeps err
+        created = true;
+        *struct_size_io = struct_size;
+    }
+    api.mem_src(c, file, (unsigned long)file_size);
+    if (api.read_header(c, 1) != 1) { api.destroy(c); return 1; }
+    // the declared layout must agree with the file: otherwise hands off
+    if (c->image_width != sw || c->image_height != shh || c->num_components != scomp) { api.destroy(c); return 2; }
+    c->out_color_space = scomp == 3 ? 2 : 1;                // JCS_RGB / JCS_GRAYSCALE (library defaults otherwise)
+    api.start(c);
+    if (c->output_width != sw || c->output_height != shh || c->output_components != scomp || c->output_scanline != 0) { api.destroy(c); return 2; }
+    const size_t row = (size_t)sw * scomp;
+    for (volatile unsigned y = 0; y < shh; y = y + 1) {
+        unsigned char* lp = line;
+        const unsigned got = api.read_scanlines(c, &lp, 1);
+        const unsigned at = c->output_scanline;             // read before the object goes away
+        if (got != 1 || at != y + 1) { api.destroy(c); return at != y + 1 ? 2 : 1; }
+        unsigned char* o = pix + row * y;
+        if (scomp == 1) std::memcpy(o, lp, row);
+        else for (unsigned x = 0; x < sw; x++) { o[3 * x] = lp[3 * x + 2]; o[3 * x + 1] = lp[3 * x + 1]; o[3 * x + 2] = lp[3 * x]; }   // RGB -> BGR
+    }
+    api.finish(c);
+    api.destroy(c);
+    return 0;
+}
+
 // 0 decoded (BGR or grey, 8 bit); 1 not decodable; 2 a flavour / library this build does not take
 int jpeg_load(const std::vector<unsigned char>& file, Pnm& p, std::vector<unsigned char>& pix) {
     const JpegApi& api = jpeg_api();
@@ -323,57 +450,13 @@ int jpeg_load(const std::vector<unsigned char>& file, Pnm& p, std::vector<unsign
     if (scomp != 1 && scomp != 3) return 2;                                 // CMYK / YCCK: left to the caller
     static std::atomic<int> struct_size_shared{656};                       // libjpeg-turbo 2.x, v8 ABI, x86-64; corrected by the handshake
     int struct_size = struct_size_shared.load();
-    std::vector<unsigned char> store;
-    JpegErrorMgr err;
-    JpegTrap trap;
-    JpegDecompressHead* volatile c = nullptr;
-    volatile bool created = false;
-    volatile int attempts = 0;
-    std::vector<unsigned char> line;
-    for (;;) {
-        store.assign((size_t)struct_size + 256, 0);
-        c = reinterpret_cast<JpegDecompressHead*>(store.data());
-        std::memset(&err, 0, sizeof err);
-        c->err = api.std_error(&err);
-        err.error_exit = jpeg_trap_exit; err.output_message = jpeg_quiet; err.emit_message = jpeg_quiet_emit;
-        c->client_data = &trap;
-        if (setjmp(trap.jb)) {
-            // JERR_BAD_STRUCT_SIZE is the only error that can arrive before the object exists: msg_parm.i[0] = expected size
-            if (!created && attempts < 2 && trap.parm0 > (int)sizeof(JpegDecompressHead) && trap.parm0 < 4096 && trap.parm0 != struct_size) {
-                struct_size = trap.parm0;
-                struct_size_shared.store(struct_size);
-                continue;
-            }
-            if (created) api.destroy(c);
-            return created ? 1 : 2;
-        }
-        attempts = attempts + 1;
-        api.create(c, 80, (size_t)struct_size);
-        c->client_data = &trap;                                             // jpeg_CreateDecompress zeroes the struct but keeps err
-        created = true;
-        break;
-    }
-    api.mem_src(c, file.data(), (unsigned long)file.size());
-    if (api.read_header(c, 1) != 1) { api.destroy(c); return 1; }
-    // the declared layout must agree with the file: otherwise hands off
-    if (c->image_width != sw || c->image_height != shh || c->num_components != scomp) { api.destroy(c); return 2; }
-    c->out_color_space = scomp == 3 ? 2 : 1;                                // JCS_RGB / JCS_GRAYSCALE (library defaults otherwise)
-    api.start(c);
-    if (c->output_width != sw || c->output_height != shh || c->output_components != scomp || c->output_scanline != 0) { api.destroy(c); return 2; }
-    p.w = (int)sw; p.h = (int)shh; p.cn = scomp; p.depth = 8; p.data_ofs = 0;
-    const size_t row = (size_t)sw * scomp;
-    pix.resize(row * shh);
-    line.resize(row);
-    for (unsigned y = 0; y < shh; y++) {
-        unsigned char* lp = line.data();
-        if (api.read_scanlines(c, &lp, 1) != 1 || c->output_scanline != y + 1) { api.destroy(c); return c->output_scanline != y + 1 ? 2 : 1; }
-        unsigned char* o = pix.data() + row * y;
-        if (scomp == 1) std::memcpy(o, lp, row);
-        else for (unsigned x = 0; x < sw; x++) { o[3 * x] = lp[3 * x + 2]; o[3 * x + 1] = lp[3 * x + 1]; o[3 * x + 2] = lp[3 * x]; }   // RGB -> BGR
-    }
-    api.finish(c);
-    api.destroy(c);
-    return 0;
+    // every buffer exists before the first libjpeg call: the geometry comes from the independent SOF parse above
+    std::vector<unsigned char> store(4096 + 256), line((size_t)sw * scomp);
+    pix.resize((size_t)sw * shh * scomp);
+    const int rc = jpeg_decode_raw(api, file.data(), file.size(), sw, shh, scomp, store.data(), store.size(), pix.data(), line.data(), &struct_size);
+    struct_size_shared.store(struct_size);
+    if (rc == 0) { p.w = (int)sw; p.h = (int)shh; p.cn = scomp; p.depth = 8; p.data_ofs = 0; }
+    return rc;
 }
 
 // 0 ok; else a status with the message set. PNM: `file` holds the file, raster at p.data_ofs; PNG: `file` holds the decoded pixels.

@@ -452,6 +452,34 @@ __global__ __launch_bounds__(256) void warp_accumulate_u16c3_kernel(WarpArgs a) 
     accp[0] = s[0]; accp[1] = s[1]; accp[2] = s[2];
 }
 
+// One thread per fold entry. A frame whose ECC failed (status != 0) gets the identity: the host reports the failure and
+// discards the sum, the table only has to be harmless.
+__global__ void warp_frames_from_ecc_kernel(const EccFrameResult* __restrict__ results, const void* const* __restrict__ src_ptrs,
+                                            int n_templates, int add_reference, int is_affine, int w, int h, size_t src_row_bytes,
+                                            WarpFrame* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_out = n_templates + (add_reference ? 1 : 0);
+    if (i >= n_out) return;
+    const int t = add_reference ? i - 1 : i;                // template index, -1: the reference frame itself
+    double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (t >= 0 && results[t].status == 0) {
+        for (int k = 0; k < 9; k++) M[k] = (double)results[t].warp[k];
+        if (is_affine) { M[6] = 0; M[7] = 0; M[8] = 1; }
+    }
+    WarpFrame wf;
+    warp_frame_make(wf, src_ptrs[t + 1], M, is_affine);
+    wf.flags = warp_frame_flags(wf.src, wf.M, src_row_bytes, w, h, is_affine);
+    out[i] = wf;
+}
+
+hipError_t launch_warp_frames_from_ecc(const EccFrameResult* results, const void* const* src_ptrs, int n_templates, int add_reference,
+                                       int is_affine, int w, int h, size_t src_row_bytes, WarpFrame* out, hipStream_t s) {
+    const int n_out = n_templates + (add_reference ? 1 : 0);
+    if (n_out <= 0) return hipSuccess;
+    warp_frames_from_ecc_kernel<<<(n_out + 63) / 64, 64, 0, s>>>(results, src_ptrs, n_templates, add_reference, is_affine, w, h, src_row_bytes, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
     dim3 grid((a.dw + 63) / 64, (a.dh + 3) / 4);
     if (depth == 8 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 &&

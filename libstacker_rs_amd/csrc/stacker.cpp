@@ -20,25 +20,6 @@ size_t frame_row_bytes(const stk_frames* f) {
     return f->row_stride_bytes ? f->row_stride_bytes : (size_t)f->width * f->channels * (f->depth / 8);
 }
 
-// 3x3 inverse by the adjugate in double (cv::invert on a 3x3 CV_64F) and invertAffineTransform.
-static void invert3x3(const double* m, double* o) {
-    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-    if (d == 0.0) { for (int i = 0; i < 9; i++) o[i] = 0; return; }
-    d = 1.0 / d;
-    double t[9] = {(m[4] * m[8] - m[5] * m[7]) * d, (m[2] * m[7] - m[1] * m[8]) * d, (m[1] * m[5] - m[2] * m[4]) * d,
-                   (m[5] * m[6] - m[3] * m[8]) * d, (m[0] * m[8] - m[2] * m[6]) * d, (m[2] * m[3] - m[0] * m[5]) * d,
-                   (m[3] * m[7] - m[4] * m[6]) * d, (m[1] * m[6] - m[0] * m[7]) * d, (m[0] * m[4] - m[1] * m[3]) * d};
-    for (int i = 0; i < 9; i++) o[i] = t[i];
-}
-static void invert_affine(const double* m, double* o) {
-    double D = m[0] * m[4] - m[1] * m[3];
-    D = D != 0 ? 1.0 / D : 0;
-    const double A11 = m[4] * D, A22 = m[0] * D, A12 = -m[1] * D, A21 = -m[3] * D;
-    o[0] = A11; o[1] = A12; o[2] = -A11 * m[2] - A12 * m[5];
-    o[3] = A21; o[4] = A22; o[5] = -A21 * m[2] - A22 * m[5];
-    o[6] = 0; o[7] = 0; o[8] = 1;
-}
-
 // Bring the frames of a stack into HBM (no copy when they already are).
 stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<const void*>& dev) {
     const size_t rb = frame_row_bytes(f), fb = rb * f->height;
@@ -99,7 +80,7 @@ void stk_destroy(stk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->frames, &ctx->ref, &ctx->blur_tmp, &ctx->templates, &ctx->slots, &ctx->queue, &ctx->results,
-                      &ctx->partials, &ctx->warpframes, &ctx->acc, &ctx->scratch, &ctx->init_warps})
+                      &ctx->partials, &ctx->warpframes, &ctx->acc, &ctx->scratch, &ctx->init_warps, &ctx->frameptrs})
         b->release();
     keypoint_workspace_destroy(ctx->kp);
     geom::hg_workspace_destroy(ctx->hg);
@@ -261,8 +242,11 @@ static stk_status ecc_prepare_reference(stk_ctx* ctx, const EccPlan& pl, const v
 // that has arrived since the last call (raising the queue's ready count behind it) and returns the number of templates
 // whose preparation has been enqueued so far; feed(true) first blocks until at least one more batch has arrived.
 using EccFeed = std::function<stk_status(bool block, int* enqueued)>;
+// `on_done`, when given, is called once the device-side queue is known to have drained, BEFORE the results travel to the
+// host: the caller enqueues there what may follow the alignment in stream order without the host's help (the fold).
+using EccDone = std::function<stk_status()>;
 static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, const float* init_warps_dev,
-                          std::vector<EccFrameResult>& res, const EccFeed* feed = nullptr) {
+                          std::vector<EccFrameResult>& res, const EccFeed* feed = nullptr, const EccDone* on_done = nullptr) {
     res.resize(pl.n_templates);
     if (pl.n_templates == 0) return STK_OK;
     // for (i = 1; i <= nIter && fabs(rho - last_rho) >= eps; i++) with rho = -1, last_rho = -eps: not even the first
@@ -352,6 +336,7 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
             if (!done && launched > max_launches)
                 return fail(ctx, STK_PROCESSING_ERROR, "ECC queue did not drain (internal error)");
         }
+        if (on_done) { const stk_status ds = (*on_done)(); if (ds) return ds; }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i + 1 < prof_used; i += 2) {
             ctx->timing.ecc_iter_ms += ev_ms(ctx->prof_ev[i], ctx->prof_ev[i + 1]);
@@ -386,33 +371,25 @@ stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w,
                             size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
                             int is_affine, float* acc, size_t acc_stride_floats, int accumulate) {
     if (wf.empty()) return STK_OK;
-    // Per frame, once: may the fast kernels divide X / W and Y / W through one shared reciprocal chain everywhere in the
-    // destination rectangle? W, X, Y are affine in (x, y): their extremes over [0, w-1] x [0, h-1] are at the corners. The
-    // kernel's own per-pixel bounds are 2^-40 < |W| and |W|, |X|, |Y| < 2^40; the corners are tested in double against
-    // 2^-36 / 2^36, which leaves the f32 rounding of the kernel's fma chains (relative 1e-7) far inside the margin. A NaN
-    // or infinite entry fails every comparison: the flag stays clear and the kernel tests pixel by pixel.
-    for (WarpFrame& f : wf) {
-        f.flags = (((uintptr_t)f.src | (uintptr_t)src_row_bytes) & 3) == 0 ? WARPFRAME_SRC_ALIGNED4 : 0;
-        if (is_affine) continue;
-        bool ok = true;
-        double wsign = 0;
-        const double cx[2] = {0.0, (double)(w - 1)}, cy[2] = {0.0, (double)(h - 1)};
-        for (int k = 0; k < 4 && ok; k++) {
-            const double x = cx[k & 1], y = cy[k >> 1];
-            const double X = (double)f.M[0] * x + (double)f.M[1] * y + (double)f.M[2];
-            const double Y = (double)f.M[3] * x + (double)f.M[4] * y + (double)f.M[5];
-            const double W = (double)f.M[6] * x + (double)f.M[7] * y + (double)f.M[8];
-            const double lim = 68719476736.0;       // 2^36
-            ok = std::fabs(W) > 1.0 / lim && std::fabs(W) < lim && std::fabs(X) < lim && std::fabs(Y) < lim;
-            if (k == 0) wsign = W; else ok = ok && (W > 0) == (wsign > 0);       // no zero crossing of W inside the rectangle
-        }
-        if (ok) f.flags |= WARPFRAME_DIV_IN_RANGE;
-    }
+    // per frame, once: the flags the fast kernels branch on (common.h: warp_frame_flags)
+    for (WarpFrame& f : wf) f.flags = warp_frame_flags(f.src, f.M, src_row_bytes, w, h, is_affine);
     HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * wf.size()));
     HIP_TRY(hipMemcpyAsync(ctx->warpframes.p, wf.data(), sizeof(WarpFrame) * wf.size(), hipMemcpyHostToDevice, ctx->stream));
+    stk_status st = warp_fold_enqueue(ctx, (int)wf.size(), depth, w, h, cn, src_row_bytes, alpha, border_mode, border_value, is_affine,
+                                      acc, acc_stride_floats, accumulate);
+    if (st) return st;
+    // the host vector may die before the copy above ran if the caller does not synchronise
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STK_OK;
+}
+
+// the fold launch itself over the n_frames entries of ctx->warpframes (device memory); asynchronous
+stk_status warp_fold_enqueue(stk_ctx* ctx, int n_frames, int depth, int w, int h, int cn, size_t src_row_bytes, double alpha,
+                             int border_mode, const double* border_value, int is_affine, float* acc, size_t acc_stride_floats,
+                             int accumulate) {
     WarpArgs a{};
     a.frames = ctx->warpframes.as<WarpFrame>();
-    a.n_frames = (int)wf.size();
+    a.n_frames = n_frames;
     a.sw = w; a.sh = h; a.cn = cn;
     a.src_stride = src_row_bytes / (depth / 8);
     a.alpha = (float)alpha;
@@ -421,19 +398,12 @@ stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w,
     a.acc = acc; a.dw = w; a.dh = h; a.acc_stride = acc_stride_floats;
     a.accumulate = accumulate; a.is_affine = is_affine; a.subpixel_bits = ctx->opt_subpixel_bits; a.tune = ctx->opt_warp_tune;
     HIP_TRY(launch_warp_accumulate(a, depth, ctx->stream));
-    // the host vector may die before the copy above ran if the caller does not synchronise
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->timing.warp_launches += 1;
-    ctx->timing.warp_frames += (int64_t)wf.size();
+    ctx->timing.warp_frames += (int64_t)n_frames;
     return STK_OK;
 }
 
-void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine) {
-    double inv[9];
-    if (is_affine) invert_affine(M, inv); else invert3x3(M, inv);
-    wf.src = src;
-    for (int k = 0; k < 9; k++) { wf.Md[k] = inv[k]; wf.M[k] = (float)inv[k]; }
-}
+void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine) { warp_frame_make(wf, src, M, is_affine); }
 
 stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c) {
     if (!im || !im->data) return fail(ctx, STK_INVALID_PARAMS, "null output image");
@@ -482,6 +452,12 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     const size_t rb = frame_row_bytes(frames), fb = rb * (size_t)h;
     const bool host_fed = frames->location == STK_HOST;
     std::vector<const void*> dev(n);
+    // whatever path leaves this function, nothing of this call may still be queued on the helper streams: a late
+    // ecc_set_ready or template launch would land in the next call's queue (destroyed after `up`, i.e. after its thread joined)
+    struct HelperStreamsIdle {
+        stk_ctx* c;
+        ~HelperStreamsIdle() { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->prep_stream); }
+    } helper_streams_idle{ctx};
     AsyncUpload up;
     if (host_fed) {
         HIP_TRY(ctx->frames.reserve(fb * (size_t)n));
@@ -534,6 +510,9 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     if ((st = prepare_reference(ctx->stream))) return bail(st);
     // (with `overlap_prep` the templates are prepared while the first frames already iterate: prep_ms is then the
     // reference's share only and the templates' time is inside align_ms)
+    // (shards of at most 2 x slots frames prepare all templates first: forcing the overlap there — the first launches then run
+    // on the frames prepared so far — was measured on a 32-frame 4K shard, round 3: 7.84-7.92 ms per step against 7.72-7.81:
+    // the late starters lengthen the tail by what the hidden preparation saves)
     const bool overlap_prep = !host_fed && !scaled && ctx->opt_prep_overlap && n - 1 > 2 * pl.n_slots;
     if (!host_fed && !overlap_prep && (st = prepare_templates(1, n - 1, ctx->stream))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -544,6 +523,36 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         seeds_dev = ctx->init_warps.as<float>();
     }
     std::vector<EccFrameResult> res;
+    // The fold follows the alignment in stream order, its frame table built on the device from the ECC results: the moment
+    // the host learns that the queue has drained it enqueues table + fold behind the launches still in flight, instead of
+    // waiting for the results, inverting 3x3 matrices and sending them back (118 us of idle GPU per 32-frame 4K shard).
+    // The results still come to the host afterwards: statistics, and the reference's `?` on a failed frame.
+    const int is_affine = params->motion_type != STK_MOTION_HOMOGRAPHY;
+    bool folded_on_device = false;
+    const EccDone fold_now = [&]() -> stk_status {
+        HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+        const int n_out = (n - 1) + (add_reference ? 1 : 0);
+        if (n_out > 0) {
+            HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * (size_t)n_out));
+            HIP_TRY(launch_warp_frames_from_ecc(ctx->results.as<EccFrameResult>(), ctx->frameptrs.as<const void*>(), n - 1, add_reference ? 1 : 0,
+                                                is_affine, w, h, rb, ctx->warpframes.as<WarpFrame>(), ctx->stream));
+            const stk_status fs = warp_fold_enqueue(ctx, n_out, frames->depth, w, h, 3, rb, alpha, STK_BORDER_CONSTANT, nullptr, is_affine,
+                                                    sum->data, image_stride_floats(sum), 0);
+            if (fs) return fs;
+        } else {
+            HIP_TRY(hipMemsetAsync(sum->data, 0, image_stride_floats(sum) * h * sizeof(float), ctx->stream));
+        }
+        HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+        folded_on_device = true;
+        return STK_OK;
+    };
+    // (the scale-down variant rescales the warps on the host first, and a run without iterations has no device results)
+    const bool device_fold = !scaled && !(crit.n_iter < 1) && std::fabs(-1.0 - (-crit.eps)) >= crit.eps && n > 1;
+    const EccDone* on_done = device_fold ? &fold_now : nullptr;
+    if (device_fold) {
+        HIP_TRY(ctx->frameptrs.reserve(sizeof(void*) * (size_t)n));
+        HIP_TRY(hipMemcpyAsync(ctx->frameptrs.p, dev.data(), sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (host_fed) {
         // the scaled path shares one grey scratch between the streams, so its templates are prepared on the compute
         // stream itself (still batch by batch as they arrive); the full-size path uses the prep stream
@@ -563,7 +572,7 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
             *enqueued = enq;
             return STK_OK;
         };
-        st = ecc_run(ctx, pl, crit, seeds_dev, res, &feed);
+        st = ecc_run(ctx, pl, crit, seeds_dev, res, &feed, on_done);
         double h2d = 0;
         const stk_status fin = up.finish(&h2d);
         if (st) return st;
@@ -588,13 +597,12 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
             *enqueued = n - 1;                                  // nothing further depends on the host
             return STK_OK;
         };
-        st = ecc_run(ctx, pl, crit, seeds_dev, res, &feed);
+        st = ecc_run(ctx, pl, crit, seeds_dev, res, &feed, on_done);
         HIP_TRY(hipStreamSynchronize(ctx->prep_stream));
         if (st) return st;
-    } else if ((st = ecc_run(ctx, pl, crit, seeds_dev, res))) return st;
-    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    } else if ((st = ecc_run(ctx, pl, crit, seeds_dev, res, nullptr, on_done))) return st;
+    if (!folded_on_device) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
 
-    const int is_affine = params->motion_type != STK_MOTION_HOMOGRAPHY;
     int first_err = -1;
     if (stats) {
         std::memset(stats, 0, sizeof(stk_frame_stats) * n);
@@ -619,9 +627,18 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         }
         if (e.status && first_err < 0) first_err = i;
     }
+    if (first_err >= 0 && folded_on_device) (void)hipStreamSynchronize(ctx->stream);     // the fold behind the queue still writes `sum`
     if (first_err >= 0)  // `?` at lib.rs:777: any OpenCV error aborts the whole stack
         return fail(ctx, STK_BACKEND_ERROR, std::string(ecc_status_message(res[first_err - 1].status)) + " [frame " + std::to_string(first_err) + "]");
 
+    if (folded_on_device) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->timing.prep_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+        ctx->timing.align_ms = ev_ms(ctx->ev[1], ctx->ev[2]);
+        ctx->timing.warp_ms = ev_ms(ctx->ev[2], ctx->ev[3]);
+        if (n_added) *n_added = (int32_t)((n - 1) + (add_reference ? 1 : 0));
+        return STK_OK;
+    }
     std::vector<WarpFrame> wf;
     wf.reserve(n);
     const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

@@ -96,20 +96,39 @@ def small_stack():
     return frames.numpy(), G
 
 
-def _write_png(path, img):
-    """Minimal PNG writer (zlib + CRC): 8-bit grey (HxW), RGB (HxWx3, given as BGR) or RGBA (HxWx4), no gamma chunk."""
+def _write_png(path, img, palette=None, bits=None):
+    """Minimal PNG writer (zlib + CRC), no gamma chunk: 8- or 16-bit grey (HxW), RGB (HxWx3, given as BGR) or RGBA (HxWx4);
+    `palette` (Nx3 RGB, uint8): HxW indices as a colour-type-3 image; `bits` in (1, 2, 4): HxW grey values < 2**bits packed."""
     import struct
     import zlib
-    a = np.asarray(img, np.uint8)
-    if a.ndim == 3 and a.shape[2] == 3:
-        a = a[..., ::-1]                                     # BGR in memory -> RGB on disk
+    a = np.asarray(img)
     h, w = a.shape[:2]
-    ctype = {2: 0, 3: 2, 4: 6}[2 if a.ndim == 2 else a.shape[2]]
-    raw = b"".join(b"\x00" + np.ascontiguousarray(a[y]).tobytes() for y in range(h))
+    extra = b""
     def chunk(tag, data):
         return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    if palette is not None:
+        depth, ctype = 8, 3
+        rows = [np.ascontiguousarray(a[y].astype(np.uint8)).tobytes() for y in range(h)]
+        extra = chunk(b"PLTE", np.ascontiguousarray(np.asarray(palette, np.uint8)).tobytes())
+    elif bits in (1, 2, 4):
+        depth, ctype = bits, 0
+        per = 8 // bits
+        rows = []
+        for y in range(h):
+            v = np.zeros(-(-w // per) * per, np.uint8)
+            v[:w] = a[y]
+            v = v.reshape(-1, per)
+            rows.append(np.sum(v.astype(np.uint16) << (bits * (per - 1 - np.arange(per))), axis=1).astype(np.uint8).tobytes())
+    else:
+        assert a.dtype in (np.uint8, np.uint16)
+        if a.ndim == 3 and a.shape[2] == 3:
+            a = a[..., ::-1]                                 # BGR in memory -> RGB on disk
+        depth = a.dtype.itemsize * 8
+        ctype = {2: 0, 3: 2, 4: 6}[2 if a.ndim == 2 else a.shape[2]]
+        rows = [np.ascontiguousarray(a[y]).astype(">u%d" % a.dtype.itemsize).tobytes() for y in range(h)]   # big-endian samples
+    raw = b"".join(b"\x00" + r for r in rows)
     with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + extra +
                 chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
 
 

@@ -176,8 +176,8 @@ def test_imread_pnm_without_a_gpu(tmp_path):
 
 
 def test_imread_png_through_runtime_libpng(tmp_path, write_png):
-    """8-bit RGB / grey PNG via libpng's simplified API loaded at run time (no headers in the image); other flavours
-    and a missing libpng -> NOT_IMPLEMENTED."""
+    """PNG via libpng's row API loaded at run time (no headers in the image): 8- and 16-bit grey / RGB, palette, low-bit
+    grey; alpha and a missing libpng -> NOT_IMPLEMENTED."""
     import ctypes.util
     lib = _ffi.load()
     rng = np.random.default_rng(1)
@@ -203,6 +203,32 @@ def test_imread_png_through_runtime_libpng(tmp_path, write_png):
     assert lib.stk_imread(None, os.fsencode(tmp_path / "g.png"), C.c_void_p(og.ctypes.data), og.nbytes, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
     assert c.value == 1 and np.array_equal(og, grey)
     assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), None, 0, None, None, None, None) == 7       # alpha: not taken
+    # 16-bit PNG (utils.rs:110-117: imread(UNCHANGED) keeps the depth -> 16UC3 / 16UC1): how a 16-bit stack (BASELINE
+    # configs[4]) arrives besides TIFF; samples byte-swapped to native order, never gamma-converted
+    c16 = rng.integers(0, 65536, (9, 14, 3), dtype=np.uint16)
+    g16 = rng.integers(0, 65536, (6, 4), dtype=np.uint16)
+    for name, img in (("c16.png", c16), ("g16.png", g16)):
+        write_png(tmp_path / name, img)
+        assert lib.stk_imread(None, os.fsencode(tmp_path / name), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+        assert (h.value, w.value) == img.shape[:2] and c.value == (1 if img.ndim == 2 else 3) and d.value == 16
+        o16 = np.empty_like(img)
+        assert lib.stk_imread(None, os.fsencode(tmp_path / name), C.c_void_p(o16.ctypes.data), o16.nbytes, None, None, None, None) == 0
+        assert np.array_equal(o16, img)
+    # palette images decode to BGR, 1/2/4-bit grey expands to 8 bit (value as stored << nothing: expand_gray scales to 0..255)
+    pal = rng.integers(0, 256, (5, 3), dtype=np.uint8)
+    idx = rng.integers(0, 5, (7, 11), dtype=np.uint8)
+    write_png(tmp_path / "p.png", idx, palette=pal)
+    op = np.empty((7, 11, 3), np.uint8)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "p.png"), C.c_void_p(op.ctypes.data), op.nbytes, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+    assert (c.value, d.value) == (3, 8) and np.array_equal(op, pal[idx][..., ::-1])
+    g2 = rng.integers(0, 4, (5, 9), dtype=np.uint8)
+    write_png(tmp_path / "g2.png", g2, bits=2)
+    og2 = np.empty((5, 9), np.uint8)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "g2.png"), C.c_void_p(og2.ctypes.data), og2.nbytes, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+    assert (c.value, d.value) == (1, 8) and np.array_equal(og2, g2 * 85)                                  # 0..3 -> 0, 85, 170, 255
+    data = (tmp_path / "c16.png").read_bytes()
+    (tmp_path / "trunc.png").write_bytes(data[: len(data) - 40])
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "trunc.png"), C.c_void_p(o16.ctypes.data), 10 ** 6, None, None, None, None) == 4   # read error: BACKEND_ERROR
     (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n garbage")
     assert lib.stk_imread(None, os.fsencode(tmp_path / "bad.png"), None, 0, None, None, None, None) == 4     # BACKEND_ERROR
 
