@@ -72,6 +72,7 @@ struct stk_ctx {
     stk::KeypointWorkspace* kp = nullptr;
     stk::geom::HgWorkspace* hg = nullptr;   // findHomography batch workspace (homography.cpp)
     stk::HostPool* host_pool = nullptr;
+    stk::HostPool* shared_pool = nullptr;  // not owned: the pool every member of a multi-device context shares (multi.cpp); overrides host_pool
     stk::MultiState* multi = nullptr;      // non-null: this context spans several devices (multi.cpp); it is member 0 itself   // persistent host threads of the keypoint path (keypoint.cpp)
     std::mutex err_mutex;
 };

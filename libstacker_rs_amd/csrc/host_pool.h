@@ -1,6 +1,7 @@
 // host_pool.h — persistent host worker pool of the keypoint path (pure C++, no HIP: also compiled by the CPU
 // sanitizer tests, tests/test_cpu_sanitize.py).
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -12,9 +13,11 @@
 namespace stk {
 
 // A small persistent pool for the per-frame host steps (spawning 12 threads twice per stack cost ~0.5 ms of a 6 ms stack).
-// Every run() owns a Job (claim counter, size, function, completion count) that the workers reach through a
-// shared_ptr snapshot taken under the lock: a worker that is still leaving the previous run can only ever touch that
-// run's (exhausted) counter, never the next run's.
+// Several threads may call run() at the same time — the member threads of a multi-device context share ONE pool sized for
+// the host, not for the number of GPUs (round 2 gave every member 12 threads of its own: 96 + 8 on an 8-GPU node with 32
+// cores). Every run() owns a Job (claim counter, size, function, completion count) on a list of active jobs; a worker
+// takes the next index of the first job that still has one. A worker reaches a job only through a shared_ptr taken under
+// the lock: one that is still leaving a finished run can only ever touch that run's (exhausted) counter, never a later run's.
 class HostPool {
 public:
     explicit HostPool(int n) {
@@ -26,19 +29,19 @@ public:
         for (auto& t : workers_) t.join();
     }
     int size() const { return (int)workers_.size(); }
-    // run fn(i) for i in [0, n); the calling thread takes part; returns when all are done
+    // run fn(i) for i in [0, n); the calling thread takes part; returns when all are done. Thread-safe.
     void run(int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         auto job = std::make_shared<Job>(n, &fn);
         {
             std::lock_guard<std::mutex> lk(m_);
-            job_ = job; gen_++;
+            jobs_.push_back(job);
         }
         cv_.notify_all();
         work(*job);
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&]() { return job->finished == job->n; });
-        job_.reset();
+        jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));
     }
 
 private:
@@ -58,25 +61,27 @@ private:
             if (++job.finished == job.n) done_.notify_all();
         }
     }
+    // a job with unclaimed indices, or null (caller holds m_)
+    std::shared_ptr<Job> pending() const {
+        for (const auto& j : jobs_)
+            if (j->next.load(std::memory_order_relaxed) < j->n) return j;
+        return nullptr;
+    }
     void loop() {
-        unsigned long long seen = 0;
         for (;;) {
             std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+                cv_.wait(lk, [&]() { return stop_ || (job = pending()) != nullptr; });
                 if (stop_) return;
-                seen = gen_;
-                job = job_;
             }
-            if (job) work(*job);
+            work(*job);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_, done_;
-    std::shared_ptr<Job> job_;
-    unsigned long long gen_ = 0;
+    std::vector<std::shared_ptr<Job>> jobs_;        // active runs (guarded by m_)
     bool stop_ = false;
 };
 

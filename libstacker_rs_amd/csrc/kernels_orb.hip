@@ -302,9 +302,12 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {          // 16-bit circul
     return ((c & (mm >> 8)) & 0xffffu) != 0;
 }
 
+#ifndef STK_FAST_PRETEST
+#define STK_FAST_PRETEST 1
+#endif
 #ifdef STK_FAST_TIMING
 __device__ unsigned long long g_fast_dbg[16];
-#define FAST_TICK(i) do { if (threadIdx.x == 0 && w > 1900 && blockIdx.x == 7 && blockIdx.y == 14 && blockIdx.z == 1) g_fast_dbg[i] = wall_clock64(); } while (0)
+#define FAST_TICK(i) do { if (threadIdx.x == 0 && w > 1900 && tile_x == 7 && tile_y == 14 && blockIdx.z == 1) g_fast_dbg[i] = wall_clock64(); } while (0)
 extern "C" void stk_debug_fast_timing(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_dbg), sizeof(g_fast_dbg)); }
 #else
 #define FAST_TICK(i) do { } while (0)
@@ -320,20 +323,34 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
     const int tid = threadIdx.x;
     FAST_TICK(0);
     if (tid == 0) { nA = 0; nB = 0; }
-    for (int i = tid; i < FT_TH * (FT_TW / 4); i += 256) {
-        const int ty = i / (FT_TW / 4), d = i - ty * (FT_TW / 4);
-        const int sy = min(max(y0 - FT_H + ty, 0), h - 1);            // values outside the image are never used
-        const int sx0 = x0 - FT_H + 4 * d;
-        const uint8_t* row = img + (size_t)sy * w;
-        uint32_t v = 0;
-        if (sx0 >= 0 && sx0 + 3 < w) v = load4_unaligned(row + sx0);
-        else {
+    {
+        // every global load of the thread is issued before the first LDS store: one memory round trip per tile instead of
+        // six in a row (the tile load was 3.3 us of a tile's 10 us, and this kernel is bound by such latencies, not by
+        // issue: waves parked half of their cycles, round 2's PMC)
+        constexpr int NIT = (FT_TH * (FT_TW / 4) + 255) / 256;
+        uint32_t v[NIT];
 #pragma unroll
-            for (int e = 0; e < 4; e++) v |= (uint32_t)row[min(max(sx0 + e, 0), w - 1)] << (8 * e);
+        for (int k = 0; k < NIT; k++) {
+            const int i = tid + 256 * k;
+            const int ii = min(i, FT_TH * (FT_TW / 4) - 1);
+            const int ty = ii / (FT_TW / 4), d = ii - ty * (FT_TW / 4);
+            const int sy = min(max(y0 - FT_H + ty, 0), h - 1);        // values outside the image are never used
+            const int sx0 = x0 - FT_H + 4 * d;
+            const uint8_t* row = img + (size_t)sy * w;
+            v[k] = 0;
+            if (sx0 >= 0 && sx0 + 3 < w) v[k] = load4_unaligned(row + sx0);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[k] |= (uint32_t)row[min(max(sx0 + e, 0), w - 1)] << (8 * e);
+            }
         }
-        *reinterpret_cast<uint32_t*>(T + ty * FT_TW + 4 * d) = v;
+        for (int i = tid; i < FT_SH * FT_SW / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = tid + 256 * k;
+            if (i < FT_TH * (FT_TW / 4)) { const int ty = i / (FT_TW / 4), d = i - ty * (FT_TW / 4); *reinterpret_cast<uint32_t*>(T + ty * FT_TW + 4 * d) = v[k]; }
+        }
     }
-    for (int i = tid; i < FT_SH * FT_SW / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
     __syncthreads();
     FAST_TICK(1);
     // score-region pixel id = sy * FT_SW + sx, sx in [0, 130), sy in [0, 34); image pixel (x0 - 1 + sx, y0 - 1 + sy);
@@ -359,6 +376,10 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
             const uint32_t ss = reinterpret_cast<const uint32_t*>(T + (sy + 6) * FT_TW)[dq];
             const uint32_t ee = __builtin_amdgcn_alignbyte(cp, c0, 3);   // columns +3: bytes c0[3] cp[0] cp[1] cp[2]
             const uint32_t ww = __builtin_amdgcn_alignbyte(c0, cm, 1);   // columns -3: bytes cm[1] cm[2] cm[3] c0[0]
+            // A 9-pixel arc of the 16-pixel ring contains one pixel of every opposite pair: N or S, and E or W. So a corner
+            // needs (N or S) AND (E or W) beyond the threshold on the same side: a necessary condition that is tighter than
+            // "two of the four" (which also admits N+S or E+W alone) and takes 3 instead of 7 logic operations per side. The
+            // exact ring test of pass 2 decides either way: same corners, same bits.
             uint32_t r[2];
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -372,8 +393,12 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
                     dk[d] = pk_sub_i16(T2, D);                           // sign set: centre darker-side test (D > thr)
                     br[d] = pk_add_i16(D, T2);                           // sign set: D < -thr
                 }
+#if STK_FAST_PRETEST == 0
                 r[half] = (((dk[0] | dk[1]) & (dk[2] | dk[3])) | (dk[0] & dk[1]) | (dk[2] & dk[3])) |
                           (((br[0] | br[1]) & (br[2] | br[3])) | (br[0] & br[1]) | (br[2] & br[3]));
+#else
+                r[half] = ((dk[0] | dk[2]) & (dk[1] | dk[3])) | ((br[0] | br[2]) & (br[1] | br[3]));
+#endif
             }
             uint32_t m = ((r[0] >> 15) & 1u) | ((r[0] >> 30) & 2u) | ((r[1] >> 13) & 4u) | ((r[1] >> 28) & 8u);
             // pixel k of this dword: sx = 4 dq - 3 + k in [0, FT_X + 2), image x = x0 - 4 + 4 dq + k in [3, w - 3), y likewise
@@ -423,7 +448,7 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
     __syncthreads();
     FAST_TICK(4);
 #ifdef STK_FAST_TIMING
-    if (threadIdx.x == 0 && w > 1900 && blockIdx.x == 7 && blockIdx.y == 14 && blockIdx.z == 1) { g_fast_dbg[8] = cntA; g_fast_dbg[9] = cntB; }
+    if (threadIdx.x == 0 && w > 1900 && tile_x == 7 && tile_y == 14 && blockIdx.z == 1) { g_fast_dbg[8] = cntA; g_fast_dbg[9] = cntB; }
 #endif
     // pass 4: strict 3x3 maxima of the interior -> histogram + candidate list (only corners can be maxima: walk list B)
     for (int i = tid; i < cntB; i += 256) {

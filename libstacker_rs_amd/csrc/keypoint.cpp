@@ -144,6 +144,11 @@ namespace {
 template <typename F>
 void parallel_for(stk_ctx* ctx, int n, int threads, F fn) {
     if (threads <= 1 || n <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    if (ctx->shared_pool) {                                  // a member of a multi-device context: one pool for all members
+        const std::function<void(int)> f = fn;
+        ctx->shared_pool->run(n, f);
+        return;
+    }
     if (!ctx->host_pool || ctx->host_pool->size() != threads - 1) {
         host_pool_destroy(ctx->host_pool);
         ctx->host_pool = new HostPool(threads - 1);          // the caller is the remaining thread

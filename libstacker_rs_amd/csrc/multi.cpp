@@ -17,6 +17,7 @@
 #include <thread>
 
 #include "context.h"
+#include "host_pool.h"
 
 using namespace stk;
 
@@ -257,6 +258,12 @@ stk_status stk_create_multi(int32_t n_devices, const int32_t* device_ids, stk_ct
         ncclResult_t r = ms->api.CommInitAll(ms->comms.data(), n_devices, ms->devices.data());
         if (r != ncclSuccess) { stk_destroy(ctx); return STK_HIP_ERROR; }
     }
+    // ONE host pool for the per-frame host steps of all members (Harris cull, match filter: keypoint.cpp), sized for the
+    // host rather than for the number of GPUs: every member thread takes part in its own runs, the pool adds the rest
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int workers = std::max(1, std::min(hw, 12 * n_devices) - n_devices);
+    ctx->host_pool = new HostPool(workers);
+    for (stk_ctx* m : ms->members) m->shared_pool = ctx->host_pool;
     (void)hipSetDevice(ctx->device);
     *out = ctx;
     return STK_OK;
