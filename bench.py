@@ -395,17 +395,17 @@ def pmc_traffic(args, world, kernel_prefix):
     import hashlib
     if args.workload != "ecc_4k" or world != 1 or args.opt or args.ecc_slots or args.frames_per_gpu:
         return None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03",):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
         try:
             allk = json.load(open(path))
             pm = next(v for k, v in allk.items() if k.startswith(kernel_prefix))
             want = allk.get("_kernel_source_sha256")
-            have = hashlib.sha256(open(os.path.join(ROOT, "libstacker_rs_amd", "csrc", "kernels_ecc_col.hip"), "rb").read()).hexdigest()
-            if want is not None and want != have:
-                return None, f"profiles/{rnd}/pmc_summary.json is from an older kernels_ecc_col.hip: ignored"
-            if want is None and rnd == "r01":
-                return None, "profiles/r01/pmc_summary.json predates this round's kernel: ignored"
+            h = hashlib.sha256()
+            for name in allk.get("_kernel_source_files", ["kernels_ecc_col.hip"]):
+                h.update(open(os.path.join(ROOT, "libstacker_rs_amd", "csrc", name), "rb").read())
+            if want is None or want != h.hexdigest():
+                return None, f"profiles/{rnd}/pmc_summary.json is from older ECC sources: ignored"
             return round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1), \
                 f"rocprofv3 --pmc, same command (profiles/{rnd}/pmc_summary.json)"
         except Exception:

@@ -6,7 +6,8 @@ the guide says to double it for 16-B-per-lane streams and to calibrate other acc
 calibration rows are in the same run: `scale_kernel` (float4 stream, 4 B read per float), `grey_blur_u8c3_kernel`
 (aligned dword loads of a BGR byte stream: 3 B/px read, 4 B/px written) and `warp_accumulate_u8c3_kernel` (unaligned
 8-byte gathers: ~3 B/px/frame). `_calibration` lists raw FETCH_SIZE / known bytes for each.
-`_kernel_source_sha256` pins the summary to the kernels_ecc_col.hip it was measured with (bench.py ignores a stale one)."""
+`_kernel_source_sha256` pins the summary to the ECC sources it was measured with — kernels_ecc_col.hip, kernels_ecc_solve.hip,
+ecc_solve_body.h, concatenated — (bench.py ignores a stale one)."""
 import collections
 import csv
 import glob
@@ -52,5 +53,10 @@ for k, v in res.items():
         v['parked_frac_of_wave_cycles'] = v.get('SQ_WAIT_ANY_per_dispatch', 0.0) / wc
         v['issue_stall_frac_of_wave_cycles'] = v.get('SQ_WAIT_INST_ANY_per_dispatch', 0.0) / wc
 out = dict(res)
-out['_kernel_source_sha256'] = hashlib.sha256(open(os.path.join(root, 'libstacker_rs_amd', 'csrc', 'kernels_ecc_col.hip'), 'rb').read()).hexdigest()
+# pins the summary to the ECC sources it was measured with: iteration pass, solve / init kernels, solve routine
+h = hashlib.sha256()
+for name in ('kernels_ecc_col.hip', 'kernels_ecc_solve.hip', 'ecc_solve_body.h'):
+    h.update(open(os.path.join(root, 'libstacker_rs_amd', 'csrc', name), 'rb').read())
+out['_kernel_source_sha256'] = h.hexdigest()
+out['_kernel_source_files'] = ['kernels_ecc_col.hip', 'kernels_ecc_solve.hip', 'ecc_solve_body.h']
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -3,7 +3,7 @@
 # Produces under gpurun_out/<tag>/: kernel-trace stats, one PMC pass for FETCH_SIZE, one for WRITE_SIZE (separate
 # passes, as MI355X_MICROARCH.md prescribes: the two do not fit the TCC slots together), one for the SQ issue / stall
 # counters, one for the vector-memory front end (TA busy, L1 tag accesses, L1->L2 requests), and a JSON summary per kernel. rocprofv3 gets the program itself after `--` (python3 bench.py ...).
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 args="--steps 2 --warmup 1 --no-cpu-baseline --host-fed-steps 0 $*"
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
