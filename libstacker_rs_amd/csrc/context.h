@@ -55,6 +55,7 @@ struct stk_ctx {
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
+    int opt_kp_lanes = 2;         // keypoint path on device-resident stacks: 2 = two halves side by side (the second on a hidden helper context), 1 = one pipeline
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
     int opt_ecc_ring = 1;         // column-walking ECC pass: frame-0 rows through the per-wave LDS ring (0: always gather from global memory)
@@ -73,6 +74,7 @@ struct stk_ctx {
     stk::geom::HgWorkspace* hg = nullptr;   // findHomography batch workspace (homography.cpp)
     stk::HostPool* host_pool = nullptr;
     stk::HostPool* shared_pool = nullptr;  // not owned: the pool every member of a multi-device context shares (multi.cpp); overrides host_pool
+    stk_ctx* lane1 = nullptr;              // hidden second context of the same device: the second lane of keypoint_align_impl (keypoint.cpp)
     stk::MultiState* multi = nullptr;      // non-null: this context spans several devices (multi.cpp); it is member 0 itself   // persistent host threads of the keypoint path (keypoint.cpp)
     std::mutex err_mutex;
 };

@@ -27,6 +27,14 @@
 
 using namespace stk;
 
+// HIP_TRY against an explicit context (the lanes of keypoint_align_impl run the same code on two contexts)
+#define HIP_TRY_C(c, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((c), STK_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
 namespace stk {
 
 struct KeypointWorkspace {
@@ -455,131 +463,214 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     }
     OrbGeometry g;
     orb_geometry(ew, eh, g);
-    // frames per ORB batch: the whole shard when it fits a 32 GiB workspace (it does for every BASELINE config), else chunks
-    int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)32 << 30) / orb_bytes_per_frame(g)));
-    batch = (n + (n + batch - 1) / batch - 1) / ((n + batch - 1) / batch);     // even batches: 256 frames as 128 + 128, not 245 + 11
-    if (host_fed) batch = std::min(batch, 1 + ctx->opt_upload_batch);      // measured at 64 x 1080p: 9-frame ORB batches 11.4 ms, 17: 12.8, 65: 15.3
-    if ((st = orb_prepare(ctx, ctx->kp, ew, eh, g, batch))) return st;
-    KeypointWorkspace* ws = ctx->kp;
-    hipStream_t s = ctx->stream;
     const int threads = ctx->opt_kp_workers;
     const bool depth16 = frames->depth == 16;
-    if (scaled) HIP_TRY(ws->gfull.reserve((size_t)w * h));
-    HIP_TRY(ws->desc0.reserve(MAX_KP * 32));
-    HIP_TRY(ws->desc.reserve(MAX_KP * 32 * (size_t)batch));
-    HIP_TRY(ws->knn.reserve(MAX_KP * 16 * (size_t)batch));
-    HIP_TRY(ws->counts.reserve(sizeof(int) * (size_t)batch));
-    if (ws->host_knn_cap < MAX_KP * 4 * (size_t)batch) {
-        if (ws->host_knn) (void)hipHostFree(ws->host_knn);
-        ws->host_knn = nullptr; ws->host_knn_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&ws->host_knn, MAX_KP * 16 * (size_t)batch, hipHostMallocDefault));
-        ws->host_knn_cap = MAX_KP * 4 * (size_t)batch;
-    }
-    // grey of a frame into level 0 of pyramid `slot`, through scale_image when scaling (utils.rs:186-214)
-    auto grey_level0 = [&](const void* frame, int slot) -> stk_status {
-        uint8_t* l0 = ws->pyr.as<uint8_t>() + (size_t)slot * g.pyr.total;
-        if (depth16) { HIP_TRY(launch_bgr16_to_grey8(frame, w, h, rb, l0, s)); return STK_OK; }   // grey16 -> (g + 128) / 257
-        if (!scaled) { HIP_TRY(launch_grey(frame, 8, w, h, rb, l0, s)); return STK_OK; }
-        HIP_TRY(launch_grey(frame, 8, w, h, rb, ws->gfull.p, s));
-        HIP_TRY(launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, l0, ew, eh, s));
-        return STK_OK;
-    };
     const double fix_sx = (double)w / (double)ew, fix_sy = (double)h / (double)eh;   // adjust_homography_for_scale_f64
 
     std::vector<KpAlign>& results = out;
     results.assign(n, KpAlign{});
-    std::vector<HostKeypoint> kp0;
-    int n0 = 0;
-    // Batches of frames go through ORB together (one launch per stage and level for the whole batch); the first batch
-    // starts with the reference frame, whose descriptors are kept in desc0 (lib.rs:161-175). Every moving frame is
-    // independent of the others (lib.rs:185-290 is the body of a Rayon map).
-    for (int b0 = 0; b0 < n; b0 += batch) {
-        const int nb = std::min(batch, n - b0);
-        if (host_fed && (st = up.wait_frame(b0 + nb - 1, s))) return st;
-        // level 0 of every pyramid of the batch: one launch when the frames are evenly spaced in memory (a tensor), else per frame
-        bool even = !scaled && nb > 1;
-        const ptrdiff_t fstep = nb > 1 ? (const uint8_t*)dev[b0 + 1] - (const uint8_t*)dev[b0] : 0;
-        for (int k = 1; even && k + 1 < nb; k++) even = ((const uint8_t*)dev[b0 + k + 1] - (const uint8_t*)dev[b0 + k]) == fstep;
-        if (even && fstep > 0 && depth16) HIP_TRY(launch_bgr16_to_grey8(dev[b0], w, h, rb, ws->pyr.as<uint8_t>(), s, nb, (size_t)fstep, g.pyr.total));
-        else if (even && fstep > 0) HIP_TRY(launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total));
-        else
-            for (int k = 0; k < nb; k++)
-                if ((st = grey_level0(dev[b0 + k], k))) return st;
-        std::vector<std::vector<HostKeypoint>> kps;
-        if ((st = orb_run(ctx, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps))) return st;   // ends synchronised
-        int first = 0;                                         // first moving frame of this batch
-        if (b0 == 0) {
-            kp0 = kps[0];
-            n0 = (int)kp0.size();
-            if (n0 > 0) HIP_TRY(hipMemcpyAsync(ws->desc0.p, ws->desc.p, (size_t)n0 * 32, hipMemcpyDeviceToDevice, s));
-            first = 1;
+
+    // Two LANES (round 3). A third of a keypoint step is host work between device stages (Harris cull and ordering, match
+    // filter, RANSAC sampling): device-resident stacks are therefore cut in two halves that run the whole pipeline side by
+    // side — the calling thread on this context, a helper thread on a hidden second context of the same device (own
+    // streams, events and workspaces: keypoint.cpp's code runs on it unchanged) — so that one half's kernels fill the
+    // other half's host gaps. Every frame is independent of the others (lib.rs:185-290 is the body of a Rayon map): the
+    // per-frame results do not depend on the lane. The reference frame belongs to lane 0; lane 1 waits for its keypoints
+    // (host) and descriptors (an event on lane 0's stream) before its first match. 64 x 1080p: 3.27-3.41 -> 3.13-3.20 ms per
+    // stack (the second lane's last host steps stay exposed); cutting each lane into 2 / 3 / 4 ORB batches to interleave
+    // more finely costs more than it hides (3.52 / 3.97 / 4.68 ms: every batch has its own synchronisations).
+    struct RefShare {
+        std::mutex m;
+        std::condition_variable cv;
+        bool ready = false, failed = false;
+        std::vector<HostKeypoint> kp0;
+        int n0 = 0;
+        const uint8_t* desc0 = nullptr;       // lane 0's device buffer
+        hipEvent_t ev = nullptr;              // recorded on lane 0's stream behind the copy into desc0
+    } ref;
+    HIP_TRY(hipEventCreateWithFlags(&ref.ev, hipEventDisableTiming));
+    struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } ref_ev_guard{ref.ev};
+
+    const bool two_lanes_cfg = ctx->opt_kp_lanes >= 2 && !host_fed && n >= 16;
+    // one lane: frames [lo, hi) of the stack through ORB -> 2-NN -> match filter -> findHomography on context `c`
+    auto run_lane = [&](stk_ctx* c, int lo, int hi) -> stk_status {
+        stk_status st;
+        (void)hipSetDevice(c->device);
+        const int cnt = hi - lo;
+        // frames per ORB batch: the whole lane when it fits a 32 GiB workspace (it does for every BASELINE config but the
+        // 1024-frame one), else chunks
+        int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, ((size_t)32 << 30) / orb_bytes_per_frame(g)));
+        batch = (cnt + (cnt + batch - 1) / batch - 1) / ((cnt + batch - 1) / batch);     // even batches: 256 frames as 128 + 128, not 245 + 11
+        if (host_fed) batch = std::min(batch, 1 + c->opt_upload_batch);      // measured at 64 x 1080p: 9-frame ORB batches 11.4 ms, 17: 12.8, 65: 15.3
+        if ((st = orb_prepare(c, c->kp, ew, eh, g, batch))) return st;
+        KeypointWorkspace* ws = c->kp;
+        hipStream_t s = c->stream;
+        if (scaled) HIP_TRY_C(c, ws->gfull.reserve((size_t)w * h));
+        HIP_TRY_C(c, ws->desc0.reserve(MAX_KP * 32));
+        HIP_TRY_C(c, ws->desc.reserve(MAX_KP * 32 * (size_t)batch));
+        HIP_TRY_C(c, ws->knn.reserve(MAX_KP * 16 * (size_t)batch));
+        HIP_TRY_C(c, ws->counts.reserve(sizeof(int) * (size_t)batch));
+        if (ws->host_knn_cap < MAX_KP * 4 * (size_t)batch) {
+            if (ws->host_knn) (void)hipHostFree(ws->host_knn);
+            ws->host_knn = nullptr; ws->host_knn_cap = 0;
+            HIP_TRY_C(c, hipHostMalloc((void**)&ws->host_knn, MAX_KP * 16 * (size_t)batch, hipHostMallocDefault));
+            ws->host_knn_cap = MAX_KP * 4 * (size_t)batch;
         }
-        const int n_mov = nb - first;
-        if (n_mov <= 0) continue;
-        const int* knn_host = ws->host_knn;
-        if (n0 > 0) {
-            // knn_match(query = frame-0 descriptors, train = frame-i descriptors, k = 2) for the whole batch  lib.rs:208-219
-            std::vector<int> cnt(nb);
-            for (int k = 0; k < nb; k++) cnt[k] = (int)kps[k].size();
-            HIP_TRY(hipMemcpyAsync(ws->counts.p, cnt.data(), sizeof(int) * nb, hipMemcpyHostToDevice, s));
-            HIP_TRY(launch_knn2_hamming(ws->desc0.as<uint8_t>(), n0, ws->desc.as<uint8_t>() + (size_t)first * MAX_KP * 32, 0,
-                                        ws->knn.as<int>(), s, n_mov, ws->counts.as<int>() + first, MAX_KP));
-            HIP_TRY(hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-        }
-        // C2/C3 on host threads: Lowe ratio, stable sort, truncate, point gather (lib.rs:221-264)
-        std::vector<std::vector<float>> from_pts(n_mov), to_pts(n_mov);
-        parallel_for(ctx, n_mov, threads, [&](int m) {
-            const int i = b0 + first + m;
-            const std::vector<HostKeypoint>& kp = kps[first + m];
-            KpAlign& R = results[i];
-            R.n_keypoints = (int)kp.size();
-            std::vector<Match> ms;
+        // grey of a frame into level 0 of pyramid `slot`, through scale_image when scaling (utils.rs:186-214)
+        auto grey_level0 = [&](const void* frame, int slot) -> stk_status {
+            uint8_t* l0 = ws->pyr.as<uint8_t>() + (size_t)slot * g.pyr.total;
+            if (depth16) { HIP_TRY_C(c, launch_bgr16_to_grey8(frame, w, h, rb, l0, s)); return STK_OK; }   // grey16 -> (g + 128) / 257
+            if (!scaled) { HIP_TRY_C(c, launch_grey(frame, 8, w, h, rb, l0, s)); return STK_OK; }
+            HIP_TRY_C(c, launch_grey(frame, 8, w, h, rb, ws->gfull.p, s));
+            HIP_TRY_C(c, launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, l0, ew, eh, s));
+            return STK_OK;
+        };
+        const std::vector<HostKeypoint>* kp0 = nullptr;       // the reference frame's keypoints / descriptors, once known
+        int n0 = 0;
+        const uint8_t* desc0 = nullptr;
+        // Batches of frames go through ORB together (one launch per stage and level for the whole batch); lane 0's first batch
+        // starts with the reference frame, whose descriptors are kept in desc0 (lib.rs:161-175).
+        for (int b0 = lo; b0 < hi; b0 += batch) {
+            const int nb = std::min(batch, hi - b0);
+            if (host_fed && (st = up.wait_frame(b0 + nb - 1, s))) return st;
+            // level 0 of every pyramid of the batch: one launch when the frames are evenly spaced in memory (a tensor), else per frame
+            bool even = !scaled && nb > 1;
+            const ptrdiff_t fstep = nb > 1 ? (const uint8_t*)dev[b0 + 1] - (const uint8_t*)dev[b0] : 0;
+            for (int k = 1; even && k + 1 < nb; k++) even = ((const uint8_t*)dev[b0 + k + 1] - (const uint8_t*)dev[b0 + k]) == fstep;
+            if (even && fstep > 0 && depth16) HIP_TRY_C(c, launch_bgr16_to_grey8(dev[b0], w, h, rb, ws->pyr.as<uint8_t>(), s, nb, (size_t)fstep, g.pyr.total));
+            else if (even && fstep > 0) HIP_TRY_C(c, launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total));
+            else
+                for (int k = 0; k < nb; k++)
+                    if ((st = grey_level0(dev[b0 + k], k))) return st;
+            std::vector<std::vector<HostKeypoint>> kps;
+            if ((st = orb_run(c, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps))) return st;   // ends synchronised
+            int first = 0;                                         // first moving frame of this batch
+            if (b0 == 0) {
+                std::lock_guard<std::mutex> lk(ref.m);
+                ref.kp0 = kps[0];
+                ref.n0 = (int)ref.kp0.size();
+                if (ref.n0 > 0) HIP_TRY_C(c, hipMemcpyAsync(ws->desc0.p, ws->desc.p, (size_t)ref.n0 * 32, hipMemcpyDeviceToDevice, s));
+                HIP_TRY_C(c, hipEventRecord(ref.ev, s));
+                ref.desc0 = ws->desc0.as<uint8_t>();
+                ref.ready = true;
+                ref.cv.notify_all();
+                first = 1;
+            }
+            if (!kp0) {
+                std::unique_lock<std::mutex> lk(ref.m);
+                ref.cv.wait(lk, [&]() { return ref.ready || ref.failed; });
+                if (ref.failed) return STK_PROCESSING_ERROR;       // lane 0 reports its own error
+                kp0 = &ref.kp0; n0 = ref.n0; desc0 = ref.desc0;
+                if (lo != 0) HIP_TRY_C(c, hipStreamWaitEvent(s, ref.ev, 0));   // the other lane's copy into desc0
+            }
+            const int n_mov = nb - first;
+            if (n_mov <= 0) continue;
+            const int* knn_host = ws->host_knn;
             if (n0 > 0) {
-                const int* knn = knn_host + (size_t)m * n0 * 4;
-                for (int q = 0; q < n0; q++) {
-                    if (knn[q * 4] < 0 || knn[q * 4 + 2] < 0) continue;                 // m.len() == 2
-                    const float d0 = (float)knn[q * 4 + 1], d1 = (float)knn[q * 4 + 3];
-                    if (d0 < params->match_ratio * d1) ms.push_back({q, knn[q * 4], d0});   // Lowe ratio lib.rs:224
+                // knn_match(query = frame-0 descriptors, train = frame-i descriptors, k = 2) for the whole batch  lib.rs:208-219
+                std::vector<int> cntv(nb);
+                for (int k = 0; k < nb; k++) cntv[k] = (int)kps[k].size();
+                HIP_TRY_C(c, hipMemcpyAsync(ws->counts.p, cntv.data(), sizeof(int) * nb, hipMemcpyHostToDevice, s));
+                HIP_TRY_C(c, launch_knn2_hamming(desc0, n0, ws->desc.as<uint8_t>() + (size_t)first * MAX_KP * 32, 0,
+                                                 ws->knn.as<int>(), s, n_mov, ws->counts.as<int>() + first, MAX_KP));
+                HIP_TRY_C(c, hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, s));
+                HIP_TRY_C(c, hipStreamSynchronize(s));
+            }
+            // C2/C3 on host threads: Lowe ratio, stable sort, truncate, point gather (lib.rs:221-264)
+            std::vector<std::vector<float>> from_pts(n_mov), to_pts(n_mov);
+            parallel_for(c, n_mov, threads, [&](int m) {
+                const int i = b0 + first + m;
+                const std::vector<HostKeypoint>& kp = kps[first + m];
+                KpAlign& R = results[i];
+                R.n_keypoints = (int)kp.size();
+                std::vector<Match> ms;
+                if (n0 > 0) {
+                    const int* knn = knn_host + (size_t)m * n0 * 4;
+                    for (int q = 0; q < n0; q++) {
+                        if (knn[q * 4] < 0 || knn[q * 4 + 2] < 0) continue;                 // m.len() == 2
+                        const float d0 = (float)knn[q * 4 + 1], d1 = (float)knn[q * 4 + 3];
+                        if (d0 < params->match_ratio * d1) ms.push_back({q, knn[q * 4], d0});   // Lowe ratio lib.rs:224
+                    }
+                    std::stable_sort(ms.begin(), ms.end(), [](const Match& a, const Match& b) { return a.d < b.d; });   // lib.rs:233
+                    const size_t keep = (size_t)std::round((float)ms.size() * params->match_keep_ratio);              // lib.rs:235
+                    if (keep < ms.size()) ms.resize(keep);
                 }
-                std::stable_sort(ms.begin(), ms.end(), [](const Match& a, const Match& b) { return a.d < b.d; });   // lib.rs:233
-                const size_t keep = (size_t)std::round((float)ms.size() * params->match_keep_ratio);              // lib.rs:235
-                if (keep < ms.size()) ms.resize(keep);
+                R.n_matches = (int)ms.size();
+                if (ms.size() < 5) return;                                                   // lib.rs:240: dropped
+                std::vector<float>& dp = from_pts[m];                                        // find_homography(dst_pts, src_pts): frame i -> frame 0
+                std::vector<float>& sp = to_pts[m];
+                sp.resize(ms.size() * 2); dp.resize(ms.size() * 2);
+                for (size_t k = 0; k < ms.size(); k++) {
+                    sp[2 * k] = (*kp0)[ms[k].q].x; sp[2 * k + 1] = (*kp0)[ms[k].q].y;        // src_pts: frame 0  lib.rs:245-253
+                    dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;                // dst_pts: frame i  lib.rs:256-264
+                }
+            });
+            // D1 on the device for the whole batch (lib.rs:267-276), D2 checks on the host (lib.rs:279-287)
+            std::vector<geom::HgProblem> probs;
+            std::vector<int> owner;
+            for (int m = 0; m < n_mov; m++)
+                if (!from_pts[m].empty()) { probs.push_back({from_pts[m].data(), to_pts[m].data(), (int)from_pts[m].size() / 2, nullptr}); owner.push_back(m); }
+            std::vector<geom::HgOutcome> outc(probs.size());
+            if (!probs.empty()) {
+                const int hst = geom::find_homography_batch(c, s, c->hg, probs.data(), (int)probs.size(), params->method,
+                                                            params->ransac_reproj_threshold, outc.data());
+                if (hst) return (stk_status)hst;
             }
-            R.n_matches = (int)ms.size();
-            if (ms.size() < 5) return;                                                   // lib.rs:240: dropped
-            std::vector<float>& dp = from_pts[m];                                        // find_homography(dst_pts, src_pts): frame i -> frame 0
-            std::vector<float>& sp = to_pts[m];
-            sp.resize(ms.size() * 2); dp.resize(ms.size() * 2);
-            for (size_t k = 0; k < ms.size(); k++) {
-                sp[2 * k] = kp0[ms[k].q].x; sp[2 * k + 1] = kp0[ms[k].q].y;              // src_pts: frame 0  lib.rs:245-253
-                dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;                // dst_pts: frame i  lib.rs:256-264
+            for (size_t k = 0; k < probs.size(); k++) {
+                KpAlign& R = results[b0 + first + owner[k]];
+                const geom::HgOutcome& o = outc[k];
+                if (o.rc != 0 || !o.found) continue;                                         // Err(_) | empty -> skip  lib.rs:275-282
+                double* H = R.H;
+                for (int q = 0; q < 9; q++) H[q] = o.H[q];
+                const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
+                if (std::fabs(det) < 1e-6) continue;                                         // lib.rs:284 / 521 (on the small-image H)
+                if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
+                R.n_inliers = o.n_inliers;
+                R.ok = true;
             }
-        });
-        // D1 on the device for the whole batch (lib.rs:267-276), D2 checks on the host (lib.rs:279-287)
-        std::vector<geom::HgProblem> probs;
-        std::vector<int> owner;
-        for (int m = 0; m < n_mov; m++)
-            if (!from_pts[m].empty()) { probs.push_back({from_pts[m].data(), to_pts[m].data(), (int)from_pts[m].size() / 2, nullptr}); owner.push_back(m); }
-        std::vector<geom::HgOutcome> outc(probs.size());
-        if (!probs.empty()) {
-            const int hst = geom::find_homography_batch(ctx, s, ctx->hg, probs.data(), (int)probs.size(), params->method,
-                                                        params->ransac_reproj_threshold, outc.data());
-            if (hst) return (stk_status)hst;
         }
-        for (size_t k = 0; k < probs.size(); k++) {
-            KpAlign& R = results[b0 + first + owner[k]];
-            const geom::HgOutcome& o = outc[k];
-            if (o.rc != 0 || !o.found) continue;                                         // Err(_) | empty -> skip  lib.rs:275-282
-            double* H = R.H;
-            for (int q = 0; q < 9; q++) H[q] = o.H[q];
-            const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
-            if (std::fabs(det) < 1e-6) continue;                                         // lib.rs:284 / 521 (on the small-image H)
-            if (scaled) { H[2] *= fix_sx; H[5] *= fix_sy; H[6] /= fix_sx; H[7] /= fix_sy; }   // utils.rs:236-239
-            R.n_inliers = o.n_inliers;
-            R.ok = true;
+        HIP_TRY_C(c, hipStreamSynchronize(s));
+        return STK_OK;
+    };
+
+    // lane 0 always; lane 1 for device-resident stacks large enough to be worth a second pipeline
+    const bool two_lanes = two_lanes_cfg;
+    const int mid = two_lanes ? (n + 1) / 2 : n;
+    stk_status st1 = STK_OK;
+    std::thread helper_thread;
+    if (two_lanes) {
+        if (!ctx->lane1) {
+            if ((st = stk_create(ctx->device, &ctx->lane1))) return fail(ctx, st, "second keypoint lane: context creation failed");
+            (void)hipSetDevice(ctx->device);
         }
+        stk_ctx* h1 = ctx->lane1;
+        h1->opt_kp_workers = ctx->opt_kp_workers; h1->opt_profile = ctx->opt_profile; h1->opt_upload_batch = ctx->opt_upload_batch;
+        timing_begin(h1);
+        // both lanes share this context's host pool (it serves concurrent callers); it must exist before the helper starts
+        if (threads > 1) {
+            if (!ctx->shared_pool && (!ctx->host_pool || ctx->host_pool->size() != threads - 1)) {
+                host_pool_destroy(ctx->host_pool);
+                ctx->host_pool = new HostPool(threads - 1);
+            }
+            h1->shared_pool = ctx->shared_pool ? ctx->shared_pool : ctx->host_pool;
+        }
+        // the frames may have been produced on this context's stream just now: the second lane's stream starts behind it
+        HIP_TRY(hipEventRecord(ctx->gate_ev, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(h1->stream, ctx->gate_ev, 0));
+        helper_thread = std::thread([&]() { st1 = run_lane(h1, mid, n); });
     }
+    st = run_lane(ctx, 0, mid);
+    if (st) { std::lock_guard<std::mutex> lk(ref.m); ref.failed = true; ref.cv.notify_all(); }
+    if (helper_thread.joinable()) helper_thread.join();
+    (void)hipSetDevice(ctx->device);
+    if (st) return st;
+    if (st1) return fail(ctx, st1, ctx->lane1 ? std::string(stk_last_error(ctx->lane1)) + " [second lane]" : "second lane failed");
+    if (two_lanes) {                                          // the FAST figures of both lanes in one place
+        ctx->timing.fast_ms = std::max(ctx->timing.fast_ms, ctx->lane1->timing.fast_ms);    // they ran side by side
+        ctx->timing.fast_launches += ctx->lane1->timing.fast_launches;
+        ctx->timing.fast_pixels += ctx->lane1->timing.fast_pixels;
+    }
+    const int n0 = ref.n0;
 
     if (n_ref_keypoints) *n_ref_keypoints = n0;
     HIP_TRY(hipStreamSynchronize(ctx->stream));

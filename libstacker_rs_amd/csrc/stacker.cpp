@@ -77,6 +77,7 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
 void stk_destroy(stk_ctx* ctx) {
     if (!ctx) return;
     multi_destroy(ctx);                    // the other devices' contexts, RCCL communicators
+    if (ctx->lane1) { stk_destroy(ctx->lane1); ctx->lane1 = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->frames, &ctx->ref, &ctx->blur_tmp, &ctx->templates, &ctx->slots, &ctx->queue, &ctx->results,
@@ -140,6 +141,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ecc_ring_lookahead") { if (value < 1 || value > 5) return fail(ctx, STK_INVALID_PARAMS, "ecc_ring_lookahead must be 1..5"); ctx->opt_ecc_ring_lookahead = (int)value; }
     else if (n == "ecc_variant") { if (value != 0 && value != 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 3 (production) or 0 (direct cross-check)"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
+    else if (n == "kp_lanes") { if (value < 1 || value > 2) return fail(ctx, STK_INVALID_PARAMS, "kp_lanes must be 1 or 2"); ctx->opt_kp_lanes = (int)value; }
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
     else if (n == "warp_tune") ctx->opt_warp_tune = (int)value;
     else if (n == "prep_stream") ctx->opt_prep_stream = value != 0;

@@ -243,3 +243,30 @@ def test_orb_tile_boundaries_bit_exact(stacker, shape):
     assert kp.shape == kpo.shape and np.array_equal(kp, kpo) and np.array_equal(de, deo)
     if min(shape) > 100:
         assert len(kp) > 50
+
+
+def test_keypoint_lanes_do_not_change_results(stacker):
+    """Device-resident stacks of >= 16 frames run as two halves side by side (kp_lanes = 2: the second half on a hidden helper
+    context of the same device, so that one half's kernels fill the other half's host steps). Frames are independent of
+    each other (lib.rs:185-290 is a Rayon map body): status, keypoint / match / inlier counts, H and the stacked image must
+    not depend on the lanes, including a frame that is dropped and repeated calls on the same context."""
+    import torch
+    from libstacker_rs_amd import KeyPointMatchParameters, RANSAC, synth
+    frames, _ = synth.make_stack(21, 640, 480, device="cuda")
+    frames[13] = 128                                        # a featureless frame in the second lane: dropped there
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    res = {}
+    try:
+        for lanes in (2, 1, 2):
+            stacker.set_option("kp_lanes", lanes)
+            d, out, stats = stacker.keypoint_match(frames, kp, return_stats=True)
+            cur = (d, out.cpu().numpy(), [(s["status"], s["n_keypoints"], s["n_matches"], s["n_inliers"]) for s in stats],
+                   np.stack([s["warp"] for s in stats]))
+            if lanes in res:
+                assert cur[0] == res[lanes][0] and np.array_equal(cur[1], res[lanes][1]) and cur[2] == res[lanes][2]
+            res[lanes] = cur
+    finally:
+        stacker.set_option("kp_lanes", 2)
+    assert res[2][0] == res[1][0] == 1
+    assert res[2][2] == res[1][2] and np.array_equal(res[2][3], res[1][3])
+    assert np.array_equal(res[2][1], res[1][1])
