@@ -197,9 +197,9 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     // 63 frames in 48 slots leave a second round of 15. So: at most 48 slots (64 up to 1080p), and the frames divided evenly
     // over the rounds that takes. Measured: 255 x 4K frames 32 slots 59.0 ms, 43 slots 57.6, 48 58.5, 64 58.3; 63 x 1080p
     // 32 slots 3.91 ms, 48 4.30, 63 3.76.
-    // Workgroups per frame: a FIXED 288 (the 1152 per 4 frames tuned in round 1), as many as the frame has 4-row groups if
-    // fewer. Fixed means that a frame's f32 summation partition depends on nothing but the frame size: its warp is
-    // bit-identical however the stack is sharded over GPUs and however many frames happen to share the launch.
+    // Workgroups per frame: a function of the FRAME SIZE only (288 at 4K, see below), so a frame's f32 summation partition
+    // depends on nothing else: its warp is bit-identical however the stack is sharded over GPUs and however many frames
+    // happen to share the launch.
     int slots = ctx->opt_ecc_slots;
     if (slots <= 0) {
         const int cap = (size_t)w * h <= (size_t)1920 * 1088 ? 64 : 48;
@@ -207,8 +207,15 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
         slots = (std::max(n_templates, 1) + rounds - 1) / rounds;
     }
     pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
-    const int units = (h + 3) / 4;                           // work units of one frame: 4-row groups (one row per wave per sweep)
-    int nb = ctx->opt_ecc_blocks > 0 ? ctx->opt_ecc_blocks / pl.n_slots : 288;
+    // Round 3: a wavefront walks ~112 rows of a 64-pixel column strip before it folds its 66 sums across the lanes (266
+    // instructions against 67 per row): 288 workgroups is that at 4K, but a 1080p frame cut into 264 left 31 rows per wave
+    // and 13 % of the pass in the folds. Now the workgroup count follows the frame: (strips x rows) / (4 waves x 112 rows),
+    // at most 288, at least 64 where the frame has that many 4-row groups (a lone small frame still wants parallelism).
+    // 64 x 1080p: 2.60 -> 2.41 ms of alignment with 72 workgroups per frame. Still a function of the frame size only.
+    const int units = (h + 3) / 4;                           // 4-row groups of the frame
+    const long long strip_rows = (long long)((w + 63) / 64) * h;
+    int nb = ctx->opt_ecc_blocks > 0 ? ctx->opt_ecc_blocks / pl.n_slots
+                                     : (int)std::max<long long>(std::min(64, units), std::min<long long>(288, strip_rows / (4 * 112)));
     nb = std::max(8, std::min(units, nb));
     nb = std::max(8, (nb / 8) * 8);                          // multiple of 8: XCD-aware block decode
     pl.nb = nb;
