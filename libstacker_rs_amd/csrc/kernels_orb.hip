@@ -683,6 +683,7 @@ __global__ __launch_bounds__(256) void gauss7_cols_kernel(const float* __restric
 // bytes at any offset), the row pass writes an f32 tile to LDS, the column pass rounds to 8 bits. Same operation
 // order as the two-kernel form above (kept for images narrower than the halo), so the result is bit-identical.
 constexpr int G7_X = 128, G7_Y = 32, G7_HX = 4, G7_R = 3;
+typedef float g7f2 __attribute__((ext_vector_type(2)));
 constexpr int G7_TW = G7_X + 2 * G7_HX;              // 136 bytes per tile row
 constexpr int G7_TH = G7_Y + 2 * G7_R;               // 38 rows
 
@@ -709,49 +710,56 @@ __global__ __launch_bounds__(256) void gauss7_fused_kernel(const uint8_t* __rest
         *reinterpret_cast<uint32_t*>(T + ty * G7_TW + 4 * d) = v;
     }
     __syncthreads();
-    // phase 2: row filter, 4 outputs per item: acc = k0 * s[x-3]; acc += k_i * s[x-3+i]
+    // phase 2: row filter, 4 outputs per item: acc = k0 * s[x-3]; acc += k_i * s[x-3+i] — the generic float row filter's
+    // operation order, a multiply and an add per tap (no contraction). Round 3: the kernel is bound by exactly this
+    // arithmetic, so outputs (0, 1) and (2, 3) go through v_pk_mul_f32 / v_pk_add_f32 as register pairs; the taps of
+    // output e + 1 are those of output e shifted by one, so every byte is converted into an even and an odd pair layout
+    // (24 conversions instead of 12) and all operands are aligned pairs: 28 packed operations instead of 52 scalar ones.
     for (int i = tid; i < G7_TH * (G7_X / 4); i += 256) {
         const int ty = i / (G7_X / 4), q = i - ty * (G7_X / 4);
         const uint32_t* tp = reinterpret_cast<const uint32_t*>(T + ty * G7_TW + 4 * q);   // bytes 4q .. 4q+11; centre of e at 4q+4+e
         const uint32_t d0 = tp[0], d1 = tp[1], d2 = tp[2];
-        float f[12];
+#define G7_B(n) ((float)(((n) < 4 ? d0 >> (8 * (n)) : (n) < 8 ? d1 >> (8 * ((n) - 4)) : d2 >> (8 * ((n) - 8))) & 255u))
+        // pe[j] = (byte 1+2j, byte 2+2j), po[j] = (byte 2+2j, byte 3+2j): tap t of outputs (0, 1) is (byte 1+t, byte 2+t)
+        const g7f2 pe[5] = {g7f2{G7_B(1), G7_B(2)}, g7f2{G7_B(3), G7_B(4)}, g7f2{G7_B(5), G7_B(6)}, g7f2{G7_B(7), G7_B(8)}, g7f2{G7_B(9), G7_B(10)}};
+        const g7f2 po[4] = {g7f2{G7_B(2), G7_B(3)}, g7f2{G7_B(4), G7_B(5)}, g7f2{G7_B(6), G7_B(7)}, g7f2{G7_B(8), G7_B(9)}};
+#undef G7_B
+        // outputs (0, 1): taps (1+t, 2+t) = t even: pe[t/2], t odd: po[(t-1)/2]; outputs (2, 3): taps (3+t, 4+t) = t even: pe[1+t/2], t odd: po[1+(t-1)/2]
+        g7f2 a01 = g7f2{k.k[0], k.k[0]} * pe[0], a23 = g7f2{k.k[0], k.k[0]} * pe[1];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            f[e] = (float)((d0 >> (8 * e)) & 255u); f[4 + e] = (float)((d1 >> (8 * e)) & 255u); f[8 + e] = (float)((d2 >> (8 * e)) & 255u);
+        for (int t = 1; t < 7; t++) {
+            const g7f2 kt = {k.k[t], k.k[t]};
+            a01 = a01 + kt * ((t & 1) ? po[(t - 1) / 2] : pe[t / 2]);
+            a23 = a23 + kt * ((t & 1) ? po[1 + (t - 1) / 2] : pe[1 + t / 2]);
         }
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float acc = k.k[0] * f[1 + e];
-#pragma unroll
-            for (int t = 1; t < 7; t++) acc += k.k[t] * f[1 + e + t];
-            o[e] = acc;
-        }
-        *reinterpret_cast<float4*>(R + ty * G7_X + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(R + ty * G7_X + 4 * q) = make_float4(a01.x, a01.y, a23.x, a23.y);
     }
     __syncthreads();
-    // phase 3: column filter; thread = 4-wide strip x 4 output rows
+    // phase 3: column filter; thread = 4-wide strip x 4 output rows; (x, y) and (z, w) as packed pairs
     {
         const int strip = tid & 31, rg = tid >> 5;
-        float4 win[4 + 2 * G7_R];
+        g7f2 wlo[4 + 2 * G7_R], whi[4 + 2 * G7_R];
 #pragma unroll
-        for (int t = 0; t < 4 + 2 * G7_R; t++) win[t] = *reinterpret_cast<const float4*>(R + (rg * 4 + t) * G7_X + 4 * strip);
+        for (int t = 0; t < 4 + 2 * G7_R; t++) {
+            const float4 v = *reinterpret_cast<const float4*>(R + (rg * 4 + t) * G7_X + 4 * strip);
+            wlo[t] = g7f2{v.x, v.y}; whi[t] = g7f2{v.z, v.w};
+        }
         const int x = x0 + 4 * strip;
         const bool aligned = (w & 3) == 0;                 // then every row of the level is dword-aligned (level bases are)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int y = y0 + rg * 4 + e;
-            const float4 c = win[e + G7_R];
-            float4 acc = make_float4(k.k[3] * c.x, k.k[3] * c.y, k.k[3] * c.z, k.k[3] * c.w);
+            const g7f2 k3 = {k.k[3], k.k[3]};
+            g7f2 alo = k3 * wlo[e + G7_R], ahi = k3 * whi[e + G7_R];
 #pragma unroll
             for (int t = 1; t <= 3; t++) {
-                const float4 a = win[e + G7_R - t], b = win[e + G7_R + t];
-                acc.x += k.k[3 + t] * (a.x + b.x); acc.y += k.k[3 + t] * (a.y + b.y);
-                acc.z += k.k[3 + t] * (a.z + b.z); acc.w += k.k[3 + t] * (a.w + b.w);
+                const g7f2 kt = {k.k[3 + t], k.k[3 + t]};
+                alo = alo + kt * (wlo[e + G7_R - t] + wlo[e + G7_R + t]);
+                ahi = ahi + kt * (whi[e + G7_R - t] + whi[e + G7_R + t]);
             }
             if (y < h && x < w) {
-                const int r0 = min(max((int)__builtin_rintf(acc.x), 0), 255), r1 = min(max((int)__builtin_rintf(acc.y), 0), 255);
-                const int r2 = min(max((int)__builtin_rintf(acc.z), 0), 255), r3 = min(max((int)__builtin_rintf(acc.w), 0), 255);
+                const int r0 = min(max((int)__builtin_rintf(alo.x), 0), 255), r1 = min(max((int)__builtin_rintf(alo.y), 0), 255);
+                const int r2 = min(max((int)__builtin_rintf(ahi.x), 0), 255), r3 = min(max((int)__builtin_rintf(ahi.y), 0), 255);
                 uint8_t* op = dst + (size_t)y * w + x;
                 if (aligned && x + 3 < w) *reinterpret_cast<uint32_t*>(op) = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)r2 << 16) | ((uint32_t)r3 << 24);
                 else {
