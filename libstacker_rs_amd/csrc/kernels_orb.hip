@@ -114,24 +114,31 @@ __global__ __launch_bounds__(256) void resize_exact_tiled_kernel(const uint8_t* 
         *reinterpret_cast<uint32_t*>(T + ty * RT_SW + 4 * d) = v;
     }
     __syncthreads();
-    // thread = 4 adjacent columns x 4 rows (rows tid/32 + 8k)
+    // thread = 4 adjacent columns x 4 rows (rows tid/32 + 8k); the columns' offsets and weights are read and prepared once
+    // for the four rows (round 3: they were re-read from LDS for every output)
     const int q = tid & 31, rg = tid >> 5;
     const bool aligned = (dw & 3) == 0;
+    int cx[4], o0[4], o1[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int tx = 4 * q + e;
+        const int ox = xo[tx];
+        cx[e] = xc[tx]; o0[e] = ox - sx_lo; o1[e] = min(ox + 1, sw - 1) - sx_lo;
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int ty = rg + 8 * k;
         const int y = y0 + ty;
         if (y >= dh) continue;
         const int oy = yo[ty], cy1 = yc[ty], cy0 = 256 - cy1;
-        const uint8_t* r0 = T + (oy - sy_lo) * RT_SW - sx_lo;
-        const uint8_t* r1 = T + (min(oy + 1, sh - 1) - sy_lo) * RT_SW - sx_lo;
+        const uint8_t* r0 = T + (oy - sy_lo) * RT_SW;
+        const uint8_t* r1 = T + (min(oy + 1, sh - 1) - sy_lo) * RT_SW;
         uint32_t out = 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int tx = 4 * q + e;
-            const int ox = xo[tx], cx1 = xc[tx], cx0 = 256 - cx1, ox1 = min(ox + 1, sw - 1);
-            const uint32_t h0 = (uint32_t)cx0 * r0[ox] + (uint32_t)cx1 * r0[ox1];
-            const uint32_t h1 = (uint32_t)cx0 * r1[ox] + (uint32_t)cx1 * r1[ox1];
+            const int cx1 = cx[e], cx0 = 256 - cx1;
+            const uint32_t h0 = (uint32_t)cx0 * r0[o0[e]] + (uint32_t)cx1 * r0[o1[e]];
+            const uint32_t h1 = (uint32_t)cx0 * r1[o0[e]] + (uint32_t)cx1 * r1[o1[e]];
             const uint32_t v = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1;
             out |= min((v + (1u << 15)) >> 16, 255u) << (8 * e);
         }
