@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -556,8 +557,19 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
             ecv.notify_all();
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < workers; t++) pool.emplace_back(work);
+    // (joined on every way out of this function: a thread that cannot be started — std::system_error — or a throwing
+    // allocation below must not leave joinable threads behind, whose destructors would terminate the process)
+    struct Joiner {
+        std::vector<std::thread> threads;
+        std::atomic<int>* next; int n;
+        ~Joiner() { next->store(n); for (auto& t : threads) if (t.joinable()) t.join(); }
+    } pool{{}, &next, n};
+    pool.threads.reserve(workers);
+    try {
+        for (int t = 0; t < workers; t++) pool.threads.emplace_back(work);
+    } catch (const std::exception&) {
+        if (pool.threads.empty()) return fail(ctx, STK_PROCESSING_ERROR, "could not start a decoder thread");
+    }                                                     // fewer threads than planned still decode everything
     FrameGate gate;
     gate.wait = [&](const void* ptr) -> bool {
         const size_t i = ((const unsigned char*)ptr - block.p) / fbytes;
@@ -573,7 +585,7 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
     ctx->frame_gate = &gate;
     st = call(&fr);
     ctx->frame_gate = nullptr;
-    for (auto& t : pool) t.join();
+    for (auto& t : pool.threads) t.join();
     if (err_status) return fail(ctx, err_status, err_msg);   // a file that could not be decoded outranks whatever the engine made of it
     return st;
 }

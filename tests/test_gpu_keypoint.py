@@ -270,3 +270,13 @@ def test_keypoint_lanes_do_not_change_results(stacker):
     assert res[2][0] == res[1][0] == 1
     assert res[2][2] == res[1][2] and np.array_equal(res[2][3], res[1][3])
     assert np.array_equal(res[2][1], res[1][1])
+    # the scale-down variant (ORB on INTER_AREA-shrunk greys, lib.rs:355-601) through both lanes as well
+    outs = []
+    try:
+        for lanes in (2, 1):
+            stacker.set_option("kp_lanes", lanes)
+            d, out, stats = stacker.keypoint_match(frames, kp, scale_down_width=400.0, return_stats=True)
+            outs.append((d, out.cpu().numpy(), np.stack([s["warp"] for s in stats])))
+    finally:
+        stacker.set_option("kp_lanes", 2)
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
