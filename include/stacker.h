@@ -177,9 +177,12 @@ void        stk_host_free(void* p);
  *   "ecc_ring_lookahead" debug: frame-0 rows the ring keeps ahead of the row being fetched (5; 1..4 make its run-time check
  *                        fire, the strips then fall back to the gather loop: stk_timing.ecc_ring_fallbacks); same bits
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
- *   "kp_lanes"           2 (default): device-resident keypoint stacks of >= 16 frames run as two halves side by side, the second
- *                        on a hidden helper context of the same device, so that one half's kernels fill the other half's host
- *                        steps; 1: one pipeline. Per-frame results do not depend on it
+ *   "kp_lanes"           4 (default; 1..8): device-resident keypoint stacks of >= 16 frames are cut into this many runs of frames (at
+ *                        least 8 each) that go through the pipeline side by side, the later ones on hidden helper contexts of
+ *                        the same device, so that one run's kernels fill the other runs' host steps; the fold follows run by
+ *                        run in stack order. 1: one pipeline. Per-frame results and the stacked image do not depend on it
+ *   "orb_patch_blur"     1 (default): ORB's 7x7 blur is computed by the descriptor kernel, for the 45 x 40 window around each kept
+ *                        keypoint only; 0: every pyramid level is blurred whole first. Same bits either way
  *   "kp_workers"         host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
  *   "warp_subpixel_bits" 0 = exact f32 coordinates (OpenCV >= 4.11 kernels); 5 = classic 1/32-px quantised table
  *                        (changes results: it selects the other OpenCV behaviour)

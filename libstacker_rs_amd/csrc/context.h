@@ -37,6 +37,8 @@ stk_ctx* multi_member(const stk_ctx* ctx, int i);
 // copies a frame. `wait` blocks until the frame at `ptr` is complete and returns false if it never will be.
 struct FrameGate { std::function<bool(const void* ptr)> wait; };
 
+constexpr int STK_MAX_KP_LANES = 8;
+
 struct stk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -55,7 +57,8 @@ struct stk_ctx {
     int opt_profile = 1;
     int opt_ecc_chunk = 4;
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
-    int opt_kp_lanes = 2;         // keypoint path on device-resident stacks: 2 = two halves side by side (the second on a hidden helper context), 1 = one pipeline
+    bool opt_orb_patch_blur = true;  // ORB: the descriptor kernel blurs the window it reads (false: blur every level whole, then sample)
+    int opt_kp_lanes = 4;         // keypoint path on device-resident stacks: the stack is cut into this many runs of frames that go through the pipeline side by side (helper contexts), 1 = one pipeline
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
     int opt_ecc_ring = 1;         // column-walking ECC pass: frame-0 rows through the per-wave LDS ring (0: always gather from global memory)
@@ -74,7 +77,8 @@ struct stk_ctx {
     stk::geom::HgWorkspace* hg = nullptr;   // findHomography batch workspace (homography.cpp)
     stk::HostPool* host_pool = nullptr;
     stk::HostPool* shared_pool = nullptr;  // not owned: the pool every member of a multi-device context shares (multi.cpp); overrides host_pool
-    stk_ctx* lane1 = nullptr;              // hidden second context of the same device: the second lane of keypoint_align_impl (keypoint.cpp)
+    stk_ctx* lanes[STK_MAX_KP_LANES - 1] = {};   // hidden helper contexts of the same device: lanes 1.. of keypoint_align_impl (keypoint.cpp)
+
     stk::MultiState* multi = nullptr;      // non-null: this context spans several devices (multi.cpp); it is member 0 itself   // persistent host threads of the keypoint path (keypoint.cpp)
     std::mutex err_mutex;
 };
@@ -102,7 +106,7 @@ stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w,
                      int is_affine, float* acc, size_t acc_stride_floats, int accumulate);
 stk_status warp_fold_enqueue(stk_ctx* ctx, int n_frames, int depth, int w, int h, int cn, size_t src_row_bytes, double alpha,
                              int border_mode, const double* border_value, int is_affine, float* acc, size_t acc_stride_floats,
-                             int accumulate);
+                             int accumulate, int first_frame = 0);
 void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine);
 stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c);
 size_t image_stride_floats(const stk_image_f32* im);
@@ -113,8 +117,12 @@ float ev_ms(hipEvent_t a, hipEvent_t b);
 stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_params* params, float scale_down_width,
                           int32_t add_reference, stk_image_f32* sum, int32_t* n_added, stk_frame_stats* stats,
                           const float* seeds, double alpha, bool allow16);
+// called with consecutive frame ranges [lo, hi) in increasing order, each once, as soon as the results of those frames (and
+// of every frame before them) are final — possibly from a helper lane's thread, never from two threads at once
+using KpFramesFinal = std::function<stk_status(int lo, int hi)>;
 struct KpAlign { bool ok = false; double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; int n_keypoints = 0, n_matches = 0, n_inliers = 0; };
 // keypoint_match's alignment half: ORB + 2-NN + ratio / sort / truncate + homography per moving frame (no fold).
 // reduce16: 16-bit frames are matched on their 8-bit reduction (g + 128) / 257 (hybrid extension only).
 stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params, float scale_down_width,
-                               bool reduce16, std::vector<KpAlign>& out, int* n_ref_keypoints, std::vector<const void*>& dev);
+                               bool reduce16, std::vector<KpAlign>& out, int* n_ref_keypoints, std::vector<const void*>& dev,
+                               const KpFramesFinal* on_final = nullptr);

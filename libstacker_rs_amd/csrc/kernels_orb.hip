@@ -694,6 +694,28 @@ typedef float g7f2 __attribute__((ext_vector_type(2)));
 constexpr int G7_TW = G7_X + 2 * G7_HX;              // 136 bytes per tile row
 constexpr int G7_TH = G7_Y + 2 * G7_R;               // 38 rows
 
+// Row filter of four adjacent outputs from the twelve bytes d0 d1 d2 (output e is centred on byte 4 + e): acc = k0 * s[x-3];
+// acc += k_i * s[x-3+i] — the generic float row filter's operation order, a multiply and an add per tap (no contraction).
+// Outputs (0, 1) and (2, 3) go through v_pk_mul_f32 / v_pk_add_f32 as register pairs; the taps of output e + 1 are those of
+// output e shifted by one, so every byte is converted into an even and an odd pair layout (24 conversions instead of 12)
+// and all operands are aligned pairs: 28 packed operations instead of 52 scalar ones.
+__device__ __forceinline__ float4 g7_row_quad(uint32_t d0, uint32_t d1, uint32_t d2, const Gauss7& k) {
+#define G7_B(n) ((float)(((n) < 4 ? d0 >> (8 * (n)) : (n) < 8 ? d1 >> (8 * ((n) - 4)) : d2 >> (8 * ((n) - 8))) & 255u))
+    // pe[j] = (byte 1+2j, byte 2+2j), po[j] = (byte 2+2j, byte 3+2j): tap t of outputs (0, 1) is (byte 1+t, byte 2+t)
+    const g7f2 pe[5] = {g7f2{G7_B(1), G7_B(2)}, g7f2{G7_B(3), G7_B(4)}, g7f2{G7_B(5), G7_B(6)}, g7f2{G7_B(7), G7_B(8)}, g7f2{G7_B(9), G7_B(10)}};
+    const g7f2 po[4] = {g7f2{G7_B(2), G7_B(3)}, g7f2{G7_B(4), G7_B(5)}, g7f2{G7_B(6), G7_B(7)}, g7f2{G7_B(8), G7_B(9)}};
+#undef G7_B
+    // outputs (0, 1): taps (1+t, 2+t) = t even: pe[t/2], t odd: po[(t-1)/2]; outputs (2, 3): taps (3+t, 4+t) = t even: pe[1+t/2], t odd: po[1+(t-1)/2]
+    g7f2 a01 = g7f2{k.k[0], k.k[0]} * pe[0], a23 = g7f2{k.k[0], k.k[0]} * pe[1];
+#pragma unroll
+    for (int t = 1; t < 7; t++) {
+        const g7f2 kt = {k.k[t], k.k[t]};
+        a01 = a01 + kt * ((t & 1) ? po[(t - 1) / 2] : pe[t / 2]);
+        a23 = a23 + kt * ((t & 1) ? po[1 + (t - 1) / 2] : pe[1 + t / 2]);
+    }
+    return make_float4(a01.x, a01.y, a23.x, a23.y);
+}
+
 __global__ __launch_bounds__(256) void gauss7_fused_kernel(const uint8_t* __restrict__ src, int w, int h, Gauss7 k,
                                                            uint8_t* __restrict__ dst, size_t pyr_stride) {
     __shared__ __attribute__((aligned(16))) uint8_t T[G7_TH * G7_TW];
@@ -717,29 +739,11 @@ __global__ __launch_bounds__(256) void gauss7_fused_kernel(const uint8_t* __rest
         *reinterpret_cast<uint32_t*>(T + ty * G7_TW + 4 * d) = v;
     }
     __syncthreads();
-    // phase 2: row filter, 4 outputs per item: acc = k0 * s[x-3]; acc += k_i * s[x-3+i] — the generic float row filter's
-    // operation order, a multiply and an add per tap (no contraction). Round 3: the kernel is bound by exactly this
-    // arithmetic, so outputs (0, 1) and (2, 3) go through v_pk_mul_f32 / v_pk_add_f32 as register pairs; the taps of
-    // output e + 1 are those of output e shifted by one, so every byte is converted into an even and an odd pair layout
-    // (24 conversions instead of 12) and all operands are aligned pairs: 28 packed operations instead of 52 scalar ones.
+    // phase 2: row filter, 4 outputs per item (g7_row_quad; round 3: the kernel is bound by exactly this arithmetic)
     for (int i = tid; i < G7_TH * (G7_X / 4); i += 256) {
         const int ty = i / (G7_X / 4), q = i - ty * (G7_X / 4);
         const uint32_t* tp = reinterpret_cast<const uint32_t*>(T + ty * G7_TW + 4 * q);   // bytes 4q .. 4q+11; centre of e at 4q+4+e
-        const uint32_t d0 = tp[0], d1 = tp[1], d2 = tp[2];
-#define G7_B(n) ((float)(((n) < 4 ? d0 >> (8 * (n)) : (n) < 8 ? d1 >> (8 * ((n) - 4)) : d2 >> (8 * ((n) - 8))) & 255u))
-        // pe[j] = (byte 1+2j, byte 2+2j), po[j] = (byte 2+2j, byte 3+2j): tap t of outputs (0, 1) is (byte 1+t, byte 2+t)
-        const g7f2 pe[5] = {g7f2{G7_B(1), G7_B(2)}, g7f2{G7_B(3), G7_B(4)}, g7f2{G7_B(5), G7_B(6)}, g7f2{G7_B(7), G7_B(8)}, g7f2{G7_B(9), G7_B(10)}};
-        const g7f2 po[4] = {g7f2{G7_B(2), G7_B(3)}, g7f2{G7_B(4), G7_B(5)}, g7f2{G7_B(6), G7_B(7)}, g7f2{G7_B(8), G7_B(9)}};
-#undef G7_B
-        // outputs (0, 1): taps (1+t, 2+t) = t even: pe[t/2], t odd: po[(t-1)/2]; outputs (2, 3): taps (3+t, 4+t) = t even: pe[1+t/2], t odd: po[1+(t-1)/2]
-        g7f2 a01 = g7f2{k.k[0], k.k[0]} * pe[0], a23 = g7f2{k.k[0], k.k[0]} * pe[1];
-#pragma unroll
-        for (int t = 1; t < 7; t++) {
-            const g7f2 kt = {k.k[t], k.k[t]};
-            a01 = a01 + kt * ((t & 1) ? po[(t - 1) / 2] : pe[t / 2]);
-            a23 = a23 + kt * ((t & 1) ? po[1 + (t - 1) / 2] : pe[1 + t / 2]);
-        }
-        *reinterpret_cast<float4*>(R + ty * G7_X + 4 * q) = make_float4(a01.x, a01.y, a23.x, a23.y);
+        *reinterpret_cast<float4*>(R + ty * G7_X + 4 * q) = g7_row_quad(tp[0], tp[1], tp[2], k);
     }
     __syncthreads();
     // phase 3: column filter; thread = 4-wide strip x 4 output rows; (x, y) and (z, w) as packed pairs
@@ -825,6 +829,82 @@ __global__ __launch_bounds__(32) void brief_kernel(const uint8_t* __restrict__ p
     desc[(size_t)kp.row * 32 + i] = (uint8_t)val;
 }
 
+// Round 3: blur only what the descriptor reads. ORB blurs every pyramid level (GaussianBlur 7x7, sigma 2) and then samples
+// 512 points per keypoint within 18.4 px of its centre (|pattern| <= 13 on either axis, rotated): 500 keypoints touch
+// 500 x 39 x 39 blurred pixels of the 27 Mpx a 4K pyramid holds. The blurred value of a pixel does not depend on who
+// computes it (fixed operation order per pixel, see gauss7_rows/cols), so ONE wave per keypoint row-filters a 45 x 40
+// window of the UNBLURRED level into LDS (the same g7_row_quad as the whole-level kernel) and column-filters, rounds and
+// compares only at the 512 sample points: bit-identical descriptors (test_gpu_stages: patch blur == whole-level blur),
+// and the whole-level blur — the second largest kernel of the keypoint path — is gone.
+constexpr int BP_R = 19;                              // sample coordinates lie in [-BP_R, BP_R] (18.38 rounded, + 1 of margin)
+constexpr int BP_ROWS = 2 * (BP_R + G7_R) + 1;        // 45 window rows: cy - 22 .. cy + 22
+constexpr int BP_TW = 48;                             // window bytes per row: cx - 23 .. cx + 24 (a halo of 4 like G7_HX)
+constexpr int BP_Q = 10;                              // 10 quads = 40 row-filtered columns: cx - 19 .. cx + 20
+constexpr int BP_RW = 4 * BP_Q;
+
+__global__ __launch_bounds__(64) void brief_patch_kernel(const uint8_t* __restrict__ pyr_img, OrbPyramid pyr, size_t pyr_stride,
+                                                         const OrbFinalKeypoint* __restrict__ kps, Gauss7 k, uint8_t* __restrict__ desc) {
+    __shared__ __attribute__((aligned(16))) uint8_t T[BP_ROWS * BP_TW];
+    __shared__ __attribute__((aligned(16))) float R[BP_ROWS * BP_RW];
+    const OrbFinalKeypoint kp = kps[blockIdx.x];
+    const int l = kp.level, w = pyr.w[l], h = pyr.h[l];
+    const uint8_t* img = pyr_img + kp.frame * pyr_stride + pyr.ofs[l];
+    const int lane = threadIdx.x;
+    const int wx0 = kp.cx - BP_R - G7_HX, wy0 = kp.cy - BP_R - G7_R;
+    // keypoints keep 31 px from the border (runByImageBorder), so the window is inside the level; the reflecting path is
+    // there for a caller who hands over other keypoints
+    const bool inside = wx0 >= 0 && wx0 + BP_TW <= w && wy0 >= 0 && wy0 + BP_ROWS <= h;
+    for (int i = lane; i < BP_ROWS * (BP_TW / 4); i += 64) {
+        const int ty = i / (BP_TW / 4), d = i - ty * (BP_TW / 4);
+        uint32_t v;
+        if (inside) v = load4_unaligned(img + (size_t)(wy0 + ty) * w + wx0 + 4 * d);
+        else {
+            const uint8_t* row = img + (size_t)refl101(wy0 + ty, h) * w;
+            v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v |= (uint32_t)row[refl101(wx0 + 4 * d + e, w)] << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(T + ty * BP_TW + 4 * d) = v;
+    }
+    __syncthreads();
+    for (int i = lane; i < BP_ROWS * BP_Q; i += 64) {
+        const int ty = i / BP_Q, q = i - ty * BP_Q;
+        const uint32_t* tp = reinterpret_cast<const uint32_t*>(T + ty * BP_TW + 4 * q);
+        *reinterpret_cast<float4*>(R + ty * BP_RW + 4 * q) = g7_row_quad(tp[0], tp[1], tp[2], k);
+    }
+    __syncthreads();
+    // lane = (descriptor byte, half): four bits = eight sample points each
+    const float a = kp.cos_a, b = kp.sin_a;
+    const int byte = lane >> 1, half = lane & 1;
+    int val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+        const signed char* p = c_orb_pattern + (byte * 8 + half * 4 + bit) * 4;
+        int t[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float px = (float)p[2 * e], py = (float)p[2 * e + 1];
+            const float x = px * a - py * b, y = px * b + py * a;
+            const int ix = min(max((int)__builtin_rintf(x), -BP_R), BP_R), iy = min(max((int)__builtin_rintf(y), -BP_R), BP_R);
+            const float* c = R + (iy + BP_R + G7_R) * BP_RW + ix + BP_R;
+            float acc = k.k[3] * c[0];
+#pragma unroll
+            for (int i = 1; i <= 3; i++) acc += k.k[3 + i] * (c[-i * BP_RW] + c[i * BP_RW]);
+            t[e] = min(max((int)__builtin_rintf(acc), 0), 255);
+        }
+        val |= (t[0] < t[1]) << bit;
+    }
+    const int other = __shfl_xor(val, 1);
+    if (half == 0) desc[(size_t)kp.row * 32 + byte] = (uint8_t)(val | (other << 4));
+}
+
+hipError_t launch_brief_patch(const uint8_t* pyr_img, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, const Gauss7& k,
+                              uint8_t* desc, hipStream_t s, size_t pyr_stride) {
+    if (n <= 0) return hipSuccess;
+    brief_patch_kernel<<<n, 64, 0, s>>>(pyr_img, pyr, pyr_stride, kps, k, desc);
+    return hipGetLastError();
+}
+
 hipError_t launch_brief(const uint8_t* pyr_blur, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, uint8_t* desc,
                         hipStream_t s, size_t pyr_stride) {
     if (n <= 0) return hipSuccess;
@@ -835,34 +915,52 @@ hipError_t launch_brief(const uint8_t* pyr_blur, const OrbPyramid& pyr, const Or
 // ---- brute-force Hamming 2-NN ---------------------------------------------------------------------------
 // blockIdx.y = train set (frame): its rows start `train_stride` rows after the previous set's, it has
 // train_counts[blockIdx.y] rows (nt when train_counts is null), and its result block is out + blockIdx.y * nq * 4.
+// Eight lanes per query, each over every eighth train row (round 3: one lane per query walked all rows alone — 120 waves of
+// a 500-step serial loop on a 1 024-SIMD device, 100 us per 16 frames, all of it on the critical path of a stack). A
+// candidate is the key (distance << 16 | train index): BFMatcher's order — smaller distance first, the earlier train
+// row on ties (a strict '<' in its sequential scan) — is the integer order of the keys, so the two smallest keys of the
+// eight partial scans, merged, are exactly the sequential scan's (best, second).
+constexpr int KNN_P = 8;
+static_assert(ORB_KNN_MAX_TRAIN <= 65536, "the train index must fit the low half of the key");
 __global__ __launch_bounds__(64) void knn2_hamming_kernel(const uint8_t* __restrict__ query, int nq,
                                                           const uint8_t* __restrict__ train, int nt, int* __restrict__ out,
                                                           const int* __restrict__ train_counts, size_t train_stride) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= nq) return;
+    const int q = blockIdx.x * (64 / KNN_P) + threadIdx.x / KNN_P, part = threadIdx.x % KNN_P;
     train += blockIdx.y * train_stride * 32; out += (size_t)blockIdx.y * nq * 4;
     if (train_counts) nt = train_counts[blockIdx.y];
-    const uint4* qa = reinterpret_cast<const uint4*>(query + (size_t)q * 32);
+    const int qc = min(q, nq - 1);                       // lanes past the last query scan along (the shuffles below want all lanes)
+    const uint4* qa = reinterpret_cast<const uint4*>(query + (size_t)qc * 32);
     const uint4 q0 = qa[0], q1 = qa[1];
-    int i0 = -1, i1 = -1, d0 = 0x7fffffff, d1 = 0x7fffffff;
-    for (int t = 0; t < nt; t++) {
+    constexpr unsigned NONE = 0x7fffffffu;
+    unsigned k0 = NONE, k1 = NONE;
+    for (int t = part; t < nt; t += KNN_P) {
         const uint4* ta = reinterpret_cast<const uint4*>(train + (size_t)t * 32);
         const uint4 t0 = ta[0], t1 = ta[1];
-        const int d = __popc(q0.x ^ t0.x) + __popc(q0.y ^ t0.y) + __popc(q0.z ^ t0.z) + __popc(q0.w ^ t0.w) +
-                      __popc(q1.x ^ t1.x) + __popc(q1.y ^ t1.y) + __popc(q1.z ^ t1.z) + __popc(q1.w ^ t1.w);
-        if (d < d1) {                      // strict '<': ties keep the earlier (lower) train index
-            if (d < d0) { i1 = i0; d1 = d0; i0 = t; d0 = d; }
-            else { i1 = t; d1 = d; }
-        }
+        const unsigned d = __popc(q0.x ^ t0.x) + __popc(q0.y ^ t0.y) + __popc(q0.z ^ t0.z) + __popc(q0.w ^ t0.w) +
+                           __popc(q1.x ^ t1.x) + __popc(q1.y ^ t1.y) + __popc(q1.z ^ t1.z) + __popc(q1.w ^ t1.w);
+        const unsigned key = (d << 16) | (unsigned)t;
+        k1 = min(k1, max(k0, key));
+        k0 = min(k0, key);
     }
-    out[q * 4 + 0] = i0; out[q * 4 + 1] = i0 >= 0 ? d0 : -1;
-    out[q * 4 + 2] = i1; out[q * 4 + 3] = i1 >= 0 ? d1 : -1;
+#pragma unroll
+    for (int m = 1; m < KNN_P; m <<= 1) {
+        const unsigned o0 = __shfl_xor(k0, m), o1 = __shfl_xor(k1, m);
+        k1 = min(max(k0, o0), min(k1, o1));
+        k0 = min(k0, o0);
+    }
+    if (part == 0 && q < nq) {
+        const int4 r = {k0 != NONE ? (int)(k0 & 0xffffu) : -1, k0 != NONE ? (int)(k0 >> 16) : -1,
+                        k1 != NONE ? (int)(k1 & 0xffffu) : -1, k1 != NONE ? (int)(k1 >> 16) : -1};
+        *reinterpret_cast<int4*>(out + (size_t)q * 4) = r;
+    }
 }
 
 hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s,
                                int n_sets, const int* train_counts, size_t train_stride) {
     if (nq <= 0 || n_sets <= 0) return hipSuccess;
-    knn2_hamming_kernel<<<dim3((nq + 63) / 64, n_sets), 64, 0, s>>>(query, nq, train, nt, out, train_counts, train_stride);
+    if (nt > ORB_KNN_MAX_TRAIN) return hipErrorInvalidValue;
+    const int per_block = 64 / KNN_P;
+    knn2_hamming_kernel<<<dim3((nq + per_block - 1) / per_block, n_sets), 64, 0, s>>>(query, nq, train, nt, out, train_counts, train_stride);
     return hipGetLastError();
 }
 

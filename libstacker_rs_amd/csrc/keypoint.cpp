@@ -10,6 +10,7 @@
 // lib.rs:284) is skipped and counted; the sum is divided by n - dropped.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -42,6 +43,8 @@ struct KeypointWorkspace {
     bool pattern_uploaded = false;
     OrbSelected* host_sel = nullptr;        // pinned: [frames][ORB_LEVELS][ORB_PACK] head of every short list
     OrbLevelState* host_states = nullptr;   // pinned: [frames][ORB_LEVELS]
+    OrbFinalKeypoint* host_final = nullptr; // pinned: the kept keypoints of a batch, back to back (read by an async copy)
+    size_t host_final_cap = 0;
     int* host_knn = nullptr;                // pinned
     size_t host_knn_cap = 0, host_frames_cap = 0;
 };
@@ -54,6 +57,7 @@ void keypoint_workspace_destroy(KeypointWorkspace* k) {
     if (k->host_sel) (void)hipHostFree(k->host_sel);
     if (k->host_states) (void)hipHostFree(k->host_states);
     if (k->host_knn) (void)hipHostFree(k->host_knn);
+    if (k->host_final) (void)hipHostFree(k->host_final);
     delete k;
 }
 
@@ -148,6 +152,12 @@ void host_pool_destroy(HostPool* p) { delete p; }
 
 namespace {
 
+// STK_KP_TRACE=1 in the environment: a line on stderr at every host-visible stage boundary of the keypoint path (context,
+// microseconds within the current second, stage) — how the lanes' host steps and the stream interleave
+static const bool KP_TRACE = getenv("STK_KP_TRACE") != nullptr;
+static double kp_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define KPT(c, what) do { if (KP_TRACE) fprintf(stderr, "[kp %p] %10.1f %s\n", (void*)(c), kp_now() - 1e6 * std::floor(kp_now() / 1e6), what); } while (0)
+
 // run `fn(i)` for i in [0, n) on the context's host pool (pure host work: no HIP calls inside)
 template <typename F>
 void parallel_for(stk_ctx* ctx, int n, int threads, F fn) {
@@ -168,7 +178,7 @@ void parallel_for(stk_ctx* ctx, int n, int threads, F fn) {
 // ORB on `n_frames` 8-bit grey images that already sit in level 0 of the workspace pyramids (frame f at
 // pyr + f * g.pyr.total). Every device stage is ONE launch per level for all frames; the host steps in between
 // (Harris cull, ordering, angles) run on `threads` host threads. Descriptors are left on the device in `desc_dev`,
-// frame f in rows [f * MAX_KP, f * MAX_KP + out[f].size()).
+// frame f in rows [f * MAX_KP, f * MAX_KP + out[f].size()) — by work still QUEUED on `s` when this returns.
 stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const OrbGeometry& g, int n_frames, int threads,
                    uint8_t* desc_dev, std::vector<std::vector<HostKeypoint>>& out) {
     uint8_t* pyr = ws->pyr.as<uint8_t>();
@@ -226,10 +236,18 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     HIP_TRY(hipEventRecord(ctx->gate_ev, ds));
     // The 7x7 blur of every level (the descriptor stage's input) does not depend on the host's Harris cull: it is queued
     // now and runs while the host works on the short lists (the host waits for the copies above only, not for the stream).
-    for (int l = 0; l < ORB_LEVELS; l++)
-        HIP_TRY(launch_gauss7(pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], g.g7, ws->tmpf.as<float>(), ws->blur.as<uint8_t>() + g.pyr.ofs[l], s,
-                              n_frames, PT, tmp_stride));
+    // (orb_patch_blur = 0 only: by default the descriptor kernel blurs the 45 x 40 window it reads, launch_brief_patch)
+    const bool patch_blur = ctx->opt_orb_patch_blur;
+    if (!patch_blur) {
+        HIP_TRY(ws->blur.reserve(g.pyr.total * (size_t)n_frames + 64));
+        HIP_TRY(ws->tmpf.reserve(tmp_stride * sizeof(float) * (size_t)n_frames));
+        for (int l = 0; l < ORB_LEVELS; l++)
+            HIP_TRY(launch_gauss7(pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], g.g7, ws->tmpf.as<float>(), ws->blur.as<uint8_t>() + g.pyr.ofs[l], s,
+                                  n_frames, PT, tmp_stride));
+    }
+    KPT(ctx, "orb: enqueued A, waiting D2H");
     HIP_TRY(hipEventSynchronize(ctx->gate_ev));
+    KPT(ctx, "orb: D2H done");
     if (timed) ctx->timing.fast_ms += ev_ms(ctx->ev[6], ctx->ev[7]);
     // rare: a level with more short-listed corners than ORB_PACK (many tied FAST scores) is fetched whole
     std::vector<std::vector<OrbSelected>> big((size_t)n_frames * ORB_LEVELS);
@@ -285,13 +303,25 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
         if (o.size() > MAX_KP) { o.resize(MAX_KP); fin.resize(MAX_KP); }
         for (size_t k = 0; k < fin.size(); k++) fin[k].row = (int)((size_t)f * MAX_KP + k);
     });
-    std::vector<OrbFinalKeypoint> all;
-    for (auto& fin : fins) all.insert(all.end(), fin.begin(), fin.end());
-    if (all.empty()) { HIP_TRY(hipStreamSynchronize(s)); return STK_OK; }
-    HIP_TRY(ws->final_kps.reserve(sizeof(OrbFinalKeypoint) * all.size()));
-    HIP_TRY(hipMemcpyAsync(ws->final_kps.p, all.data(), sizeof(OrbFinalKeypoint) * all.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)all.size(), desc_dev, s, PT));
-    HIP_TRY(hipStreamSynchronize(s));     // `all` is read by the async copy above
+    KPT(ctx, "orb: cull done");
+    // all frames' keypoints back to back in the workspace's pinned buffer: the copy and the descriptor kernel are only
+    // ENQUEUED here — the caller synchronises the stream once, behind whatever it queues next (the 2-NN match)
+    size_t n_all = 0;
+    for (auto& fin : fins) n_all += fin.size();
+    if (n_all == 0) return STK_OK;
+    if (ws->host_final_cap < n_all) {
+        if (ws->host_final) (void)hipHostFree(ws->host_final);
+        ws->host_final = nullptr; ws->host_final_cap = 0;
+        const size_t cap = std::max(n_all + n_all / 4, (size_t)1024);
+        HIP_TRY(hipHostMalloc((void**)&ws->host_final, sizeof(OrbFinalKeypoint) * cap, hipHostMallocDefault));
+        ws->host_final_cap = cap;
+    }
+    n_all = 0;
+    for (auto& fin : fins) { std::memcpy(ws->host_final + n_all, fin.data(), sizeof(OrbFinalKeypoint) * fin.size()); n_all += fin.size(); }
+    HIP_TRY(ws->final_kps.reserve(sizeof(OrbFinalKeypoint) * n_all));
+    HIP_TRY(hipMemcpyAsync(ws->final_kps.p, ws->host_final, sizeof(OrbFinalKeypoint) * n_all, hipMemcpyHostToDevice, s));
+    if (patch_blur) HIP_TRY(launch_brief_patch(pyr, g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)n_all, g.g7, desc_dev, s, PT));
+    else HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)n_all, desc_dev, s, PT));
     return STK_OK;
 }
 
@@ -300,8 +330,6 @@ stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeo
     const size_t F = (size_t)std::max(n_frames, 1);
     HIP_TRY(ws->pyr.reserve(g.pyr.total * F + 64));       // + slack: the tiled kernels read whole aligned dwords
     HIP_TRY(ws->score.reserve(g.pyr.total * F + 64));
-    HIP_TRY(ws->blur.reserve(g.pyr.total * F + 64));
-    HIP_TRY(ws->tmpf.reserve((size_t)w * h * sizeof(float) * F));
     HIP_TRY(ws->cand.reserve(g.cand_total * sizeof(OrbCandidate) * F));
     HIP_TRY(ws->sel.reserve(sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS * F));
     HIP_TRY(ws->states.reserve(sizeof(OrbLevelState) * ORB_LEVELS * F));
@@ -320,7 +348,7 @@ stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeo
 
 // device bytes one frame needs in the batched ORB workspace (pyramid x3, f32 scratch, candidates, short lists, descriptors)
 size_t orb_bytes_per_frame(const OrbGeometry& g) {
-    return g.pyr.total * 3 + (size_t)g.pyr.w[0] * g.pyr.h[0] * sizeof(float) + g.cand_total * sizeof(OrbCandidate) +
+    return g.pyr.total * 2 + g.cand_total * sizeof(OrbCandidate) +
            sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS + MAX_KP * 32;
 }
 
@@ -388,6 +416,7 @@ stk_status stk_bf_knn2_hamming(stk_ctx* ctx, const uint8_t* query, int32_t n_que
     if (!ctx) return STK_INVALID_PARAMS;
     if (n_query < 0 || n_train < 0 || (n_query && (!query || !out)) || (n_train && !train)) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
     if (n_query == 0) return STK_OK;
+    if (n_train > ORB_KNN_MAX_TRAIN) return fail(ctx, STK_INVALID_PARAMS, "bf_knn2_hamming: more than 65536 train rows");
     (void)hipSetDevice(ctx->device);
     KeypointWorkspace* ws = ctx->kp;
     HIP_TRY(ws->desc0.reserve((size_t)n_query * 32));
@@ -421,7 +450,8 @@ stk_status stk_find_homography(stk_ctx* ctx, const float* src_pts, const float* 
 }  // extern "C"
 
 stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk_keypoint_params* params, float scale_down_width,
-                               bool reduce16, std::vector<KpAlign>& out, int* n_ref_keypoints, std::vector<const void*>& dev) {
+                               bool reduce16, std::vector<KpAlign>& out, int* n_ref_keypoints, std::vector<const void*>& dev,
+                               const KpFramesFinal* on_final) {
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
     if (!params) return fail(ctx, STK_INVALID_PARAMS, "null params");
@@ -470,15 +500,18 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     std::vector<KpAlign>& results = out;
     results.assign(n, KpAlign{});
 
-    // Two LANES (round 3). A third of a keypoint step is host work between device stages (Harris cull and ordering, match
-    // filter, RANSAC sampling): device-resident stacks are therefore cut in two halves that run the whole pipeline side by
-    // side — the calling thread on this context, a helper thread on a hidden second context of the same device (own
-    // streams, events and workspaces: keypoint.cpp's code runs on it unchanged) — so that one half's kernels fill the
-    // other half's host gaps. Every frame is independent of the others (lib.rs:185-290 is the body of a Rayon map): the
-    // per-frame results do not depend on the lane. The reference frame belongs to lane 0; lane 1 waits for its keypoints
-    // (host) and descriptors (an event on lane 0's stream) before its first match. 64 x 1080p: 3.27-3.41 -> 3.13-3.20 ms per
-    // stack (the second lane's last host steps stay exposed); cutting each lane into 2 / 3 / 4 ORB batches to interleave
-    // more finely costs more than it hides (3.52 / 3.97 / 4.68 ms: every batch has its own synchronisations).
+    // LANES (round 3). A third of a keypoint step is host work between device stages (Harris cull and ordering, match
+    // filter, RANSAC sampling): device-resident stacks are therefore cut into kp_lanes runs of frames (4; at least 8
+    // frames each) that go through the whole pipeline side by side — the calling thread on this context, helper threads on
+    // hidden contexts of the same device (own streams, events and workspaces: keypoint.cpp's code runs on them unchanged) —
+    // so that one lane's kernels fill the other lanes' host gaps. Every frame is independent of the others (lib.rs:185-290
+    // is the body of a Rayon map): the per-frame results do not depend on the lane. The reference frame belongs to lane 0;
+    // the other lanes wait for its keypoints (host) and descriptors (an event on lane 0's stream) before their first match.
+    // The device takes the lanes' FAST launches (each fills it) more or less one after the other, so the lanes drift apart
+    // by themselves; what stays exposed is the LAST lane's host tail (cull -> BRIEF -> 2-NN -> filter -> RANSAC, ~0.75 ms
+    // of latency for ~0.15 ms of kernels), which is why more, shorter lanes help up to 4-6 and the fold follows the lanes
+    // (`on_final`). 64 x 1080p: one pipeline 3.3-3.4 ms, 2 lanes 3.1-3.2, 4 lanes + following fold 2.8-2.9 ms per stack.
+    // Cutting a LANE into several ORB batches instead costs more than it hides (3.5-4.7 ms: every batch has its own syncs).
     struct RefShare {
         std::mutex m;
         std::condition_variable cv;
@@ -543,7 +576,8 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 for (int k = 0; k < nb; k++)
                     if ((st = grey_level0(dev[b0 + k], k))) return st;
             std::vector<std::vector<HostKeypoint>> kps;
-            if ((st = orb_run(c, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps))) return st;   // ends synchronised
+            KPT(c, "lane: batch start");
+            if ((st = orb_run(c, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps))) return st;   // descriptors: queued on s
             int first = 0;                                         // first moving frame of this batch
             if (b0 == 0) {
                 std::lock_guard<std::mutex> lk(ref.m);
@@ -576,6 +610,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 HIP_TRY_C(c, hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, s));
                 HIP_TRY_C(c, hipStreamSynchronize(s));
             }
+            KPT(c, "lane: knn done");
             // C2/C3 on host threads: Lowe ratio, stable sort, truncate, point gather (lib.rs:221-264)
             std::vector<std::vector<float>> from_pts(n_mov), to_pts(n_mov);
             parallel_for(c, n_mov, threads, [&](int m) {
@@ -605,6 +640,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                     dp[2 * k] = kp[ms[k].t].x; dp[2 * k + 1] = kp[ms[k].t].y;                // dst_pts: frame i  lib.rs:256-264
                 }
             });
+            KPT(c, "lane: match host done");
             // D1 on the device for the whole batch (lib.rs:267-276), D2 checks on the host (lib.rs:279-287)
             std::vector<geom::HgProblem> probs;
             std::vector<int> owner;
@@ -616,6 +652,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                                                             params->ransac_reproj_threshold, outc.data());
                 if (hst) return (stk_status)hst;
             }
+            KPT(c, "lane: homography done");
             for (size_t k = 0; k < probs.size(); k++) {
                 KpAlign& R = results[b0 + first + owner[k]];
                 const geom::HgOutcome& o = outc[k];
@@ -633,42 +670,76 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
         return STK_OK;
     };
 
-    // lane 0 always; lane 1 for device-resident stacks large enough to be worth a second pipeline
-    const bool two_lanes = two_lanes_cfg;
-    const int mid = two_lanes ? (n + 1) / 2 : n;
-    stk_status st1 = STK_OK;
-    std::thread helper_thread;
-    if (two_lanes) {
-        if (!ctx->lane1) {
-            if ((st = stk_create(ctx->device, &ctx->lane1))) return fail(ctx, st, "second keypoint lane: context creation failed");
-            (void)hipSetDevice(ctx->device);
+    // lane 0 always (the calling thread); helper lanes for device-resident stacks large enough to be worth more pipelines
+    const int n_lanes = two_lanes_cfg ? std::max(2, std::min({ctx->opt_kp_lanes, STK_MAX_KP_LANES, n / 8})) : 1;
+    std::vector<int> cut(n_lanes + 1);
+    for (int k = 0; k <= n_lanes; k++) cut[k] = (int)(((int64_t)n * k + n_lanes - 1) / n_lanes);
+    std::vector<stk_status> lane_st(n_lanes, STK_OK);
+    // frames become final lane by lane; `on_final` gets them in stack order (a lane's range once every earlier lane is through)
+    struct FinalOrder { std::mutex m; std::vector<int> done; int next = 0; stk_status st = STK_OK; } fin;
+    fin.done.assign(n_lanes, 0);
+    auto lane_finished = [&](int k, stk_status lane_status) {
+        if (!on_final) return;
+        std::lock_guard<std::mutex> lk(fin.m);
+        fin.done[k] = lane_status == STK_OK ? 1 : -1;
+        while (fin.next < n_lanes && fin.done[fin.next] == 1 && fin.st == STK_OK) {
+            fin.st = (*on_final)(cut[fin.next], cut[fin.next + 1]);
+            fin.next++;
         }
-        stk_ctx* h1 = ctx->lane1;
-        h1->opt_kp_workers = ctx->opt_kp_workers; h1->opt_profile = ctx->opt_profile; h1->opt_upload_batch = ctx->opt_upload_batch;
-        timing_begin(h1);
-        // both lanes share this context's host pool (it serves concurrent callers); it must exist before the helper starts
-        if (threads > 1) {
-            if (!ctx->shared_pool && (!ctx->host_pool || ctx->host_pool->size() != threads - 1)) {
-                host_pool_destroy(ctx->host_pool);
-                ctx->host_pool = new HostPool(threads - 1);
-            }
-            h1->shared_pool = ctx->shared_pool ? ctx->shared_pool : ctx->host_pool;
+    };
+    std::vector<std::thread> helpers;
+    struct LaneJoin {                                        // also when lane 0 leaves by an exception: wake the helpers, then join them
+        std::vector<std::thread>& t; RefShare& r;
+        ~LaneJoin() {
+            bool any = false;
+            for (auto& th : t) any = any || th.joinable();
+            if (!any) return;
+            { std::lock_guard<std::mutex> lk(r.m); if (!r.ready) r.failed = true; }
+            r.cv.notify_all();
+            for (auto& th : t) if (th.joinable()) th.join();
         }
-        // the frames may have been produced on this context's stream just now: the second lane's stream starts behind it
+    } lane_join{helpers, ref};
+    if (n_lanes > 1) {
+        // all lanes share this context's host pool (it serves concurrent callers); it must exist before a helper starts
+        if (threads > 1 && !ctx->shared_pool && (!ctx->host_pool || ctx->host_pool->size() != threads - 1)) {
+            host_pool_destroy(ctx->host_pool);
+            ctx->host_pool = new HostPool(threads - 1);
+        }
+        // the frames may have been produced on this context's stream just now: the helpers' streams start behind it
         HIP_TRY(hipEventRecord(ctx->gate_ev, ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(h1->stream, ctx->gate_ev, 0));
-        helper_thread = std::thread([&]() { st1 = run_lane(h1, mid, n); });
+        helpers.reserve(n_lanes - 1);
+        for (int k = 1; k < n_lanes; k++) {
+            stk_ctx*& hk = ctx->lanes[k - 1];
+            if (!hk) {
+                if ((st = stk_create(ctx->device, &hk))) return fail(ctx, st, "keypoint lane: helper context creation failed");
+                (void)hipSetDevice(ctx->device);
+            }
+            hk->opt_kp_workers = ctx->opt_kp_workers; hk->opt_orb_patch_blur = ctx->opt_orb_patch_blur; hk->opt_profile = ctx->opt_profile;
+            hk->opt_upload_batch = ctx->opt_upload_batch;
+            timing_begin(hk);
+            if (threads > 1) hk->shared_pool = ctx->shared_pool ? ctx->shared_pool : ctx->host_pool;
+            HIP_TRY(hipStreamWaitEvent(hk->stream, ctx->gate_ev, 0));
+            stk_ctx* h = hk;
+            helpers.emplace_back([&, h, k]() {
+                try { lane_st[k] = run_lane(h, cut[k], cut[k + 1]); lane_finished(k, lane_st[k]); }
+                catch (const std::exception& e) { lane_st[k] = fail(h, STK_PROCESSING_ERROR, std::string("helper lane: ") + e.what()); }
+            });
+        }
     }
-    st = run_lane(ctx, 0, mid);
+    st = run_lane(ctx, 0, cut[1]);
     if (st) { std::lock_guard<std::mutex> lk(ref.m); ref.failed = true; ref.cv.notify_all(); }
-    if (helper_thread.joinable()) helper_thread.join();
+    lane_finished(0, st);
+    for (auto& th : helpers) if (th.joinable()) th.join();
     (void)hipSetDevice(ctx->device);
     if (st) return st;
-    if (st1) return fail(ctx, st1, ctx->lane1 ? std::string(stk_last_error(ctx->lane1)) + " [second lane]" : "second lane failed");
-    if (two_lanes) {                                          // the FAST figures of both lanes in one place
-        ctx->timing.fast_ms = std::max(ctx->timing.fast_ms, ctx->lane1->timing.fast_ms);    // they ran side by side
-        ctx->timing.fast_launches += ctx->lane1->timing.fast_launches;
-        ctx->timing.fast_pixels += ctx->lane1->timing.fast_pixels;
+    for (int k = 1; k < n_lanes; k++)
+        if (lane_st[k]) return fail(ctx, lane_st[k], std::string(stk_last_error(ctx->lanes[k - 1])) + " [helper lane]");
+    if (fin.st) return fin.st;
+    for (int k = 1; k < n_lanes; k++) {                       // the FAST figures of all lanes in one place
+        const stk_ctx* hk = ctx->lanes[k - 1];
+        ctx->timing.fast_ms = std::max(ctx->timing.fast_ms, hk->timing.fast_ms);    // they ran side by side
+        ctx->timing.fast_launches += hk->timing.fast_launches;
+        ctx->timing.fast_pixels += hk->timing.fast_pixels;
     }
     const int n0 = ref.n0;
 
@@ -697,39 +768,59 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     std::vector<KpAlign> results;
     int n0 = 0;
     std::vector<const void*> dev;
-    if ((st = keypoint_align_impl(ctx, frames, params, scale_down_width, false, results, &n0, dev))) return st;
     const size_t rb = frame_row_bytes(frames);
+    // The fold follows the alignment lane by lane (KpFramesFinal): the frames of a lane are warped into the sum as soon as
+    // that lane and every earlier one are through, while later lanes are still in their host steps. Launches accumulate in
+    // stack order, so the f32 sum is the one a single launch over all frames gives (each pixel: ((0 + f_a) + f_b) + ...).
+    std::vector<WarpFrame> wf(n);                               // entries [0, n_wf) are used; never reallocated (async copies read it)
+    struct StreamIdle { hipStream_t s; ~StreamIdle() { (void)hipStreamSynchronize(s); } } wf_outlives_its_copies{ctx->stream};
+    int n_wf = 0, dropped = 0;
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * (size_t)n));
+    const bool timed = ctx->opt_profile >= 1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_ev;
+    struct EvGuard { std::vector<std::pair<hipEvent_t, hipEvent_t>>& v; ~EvGuard() { for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } } } fold_ev_guard{fold_ev};
+    const KpFramesFinal fold_range = [&](int lo, int hi) -> stk_status {
+        (void)hipSetDevice(ctx->device);
+        const int first = n_wf;
+        for (int i = lo; i < hi; i++) {
+            if (i == 0) { if (add_reference) make_warp_frame(wf[n_wf++], dev[0], I3, 0); continue; }
+            if (!results[i].ok) { dropped++; continue; }
+            make_warp_frame(wf[n_wf++], dev[i], results[i].H, 0);
+        }
+        const int cnt = n_wf - first;
+        if (cnt == 0) return STK_OK;
+        for (int k = first; k < n_wf; k++) wf[k].flags = warp_frame_flags(wf[k].src, wf[k].M, rb, w, h, 0);
+        if (timed) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            fold_ev.emplace_back(a, b);
+            HIP_TRY(hipEventRecord(a, ctx->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->warpframes.as<WarpFrame>() + first, wf.data() + first, sizeof(WarpFrame) * (size_t)cnt, hipMemcpyHostToDevice, ctx->stream));
+        const stk_status fs = warp_fold_enqueue(ctx, cnt, 8, w, h, 3, rb, 1.0 / 255.0, params->border_mode, params->border_value, 0, sum->data,
+                                                image_stride_floats(sum), first > 0 ? 1 : 0, first);
+        if (fs) return fs;
+        if (timed) HIP_TRY(hipEventRecord(fold_ev.back().second, ctx->stream));
+        return STK_OK;
+    };
+    if ((st = keypoint_align_impl(ctx, frames, params, scale_down_width, false, results, &n0, dev, &fold_range))) return st;
     if (stats) {
         std::memset(stats, 0, sizeof(stk_frame_stats) * n);
         stats[0].n_keypoints = n0; stats[0].warp[0] = stats[0].warp[4] = stats[0].warp[8] = 1;
-    }
-
-    // fold order = frame order: the f32 sum is reproducible
-    std::vector<WarpFrame> wf;
-    wf.reserve(n);
-    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (add_reference) { wf.emplace_back(); make_warp_frame(wf.back(), dev[0], I3, 0); }
-    int dropped = 0;
-    for (int i = 1; i < n; i++) {
-        const KpAlign& R = results[i];
-        if (stats) {
+        for (int i = 1; i < n; i++) {
+            const KpAlign& R = results[i];
             stats[i].status = R.ok ? 0 : 1; stats[i].n_keypoints = R.n_keypoints; stats[i].n_matches = R.n_matches; stats[i].n_inliers = R.n_inliers;
             for (int k = 0; k < 9; k++) stats[i].warp[k] = R.H[k];
         }
-        if (!R.ok) { dropped++; continue; }
-        wf.emplace_back();
-        make_warp_frame(wf.back(), dev[i], R.H, 0);
     }
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    if (wf.empty()) HIP_TRY(hipMemsetAsync(sum->data, 0, image_stride_floats(sum) * h * sizeof(float), ctx->stream));
-    if ((st = warp_fold(ctx, wf, 8, w, h, 3, rb, 1.0 / 255.0, params->border_mode, params->border_value, 0, sum->data,
-                        image_stride_floats(sum), 0))) return st;
-    HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    if (n_wf == 0) HIP_TRY(hipMemsetAsync(sum->data, 0, image_stride_floats(sum) * h * sizeof(float), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->timing.align_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
-    ctx->timing.warp_ms = ev_ms(ctx->ev[2], ctx->ev[3]);
-    if (n_added) *n_added = (int32_t)wf.size();
+    ctx->timing.align_ms = ev_ms(ctx->ev[0], ctx->ev[1]);       // includes the folds that ran under later lanes
+    ctx->timing.warp_ms = 0;
+    for (auto& p : fold_ev) ctx->timing.warp_ms += ev_ms(p.first, p.second);
+    if (n_added) *n_added = (int32_t)n_wf;
     if (n_dropped) *n_dropped = dropped;
     return STK_OK;
 }

@@ -8,6 +8,7 @@ constexpr int ORB_LEVELS = 8;
 constexpr int ORB_NFEATURES = 500;
 constexpr int ORB_EDGE = 31;
 constexpr int ORB_FAST_THRESHOLD = 20;
+constexpr int ORB_KNN_MAX_TRAIN = 65536; // train rows per set of launch_knn2_hamming (the index shares a 32-bit key with the distance)
 constexpr int ORB_SEL_CAP = 4096;        // short-list entries per level (2 n_l + ties)
 
 struct OrbCandidate { int xy; int score; };                               // x | y << 16
@@ -52,6 +53,9 @@ hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, floa
 hipError_t upload_orb_pattern(const signed char* p);
 hipError_t launch_brief(const uint8_t* pyr_blur, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, uint8_t* desc,
                         hipStream_t s, size_t pyr_stride = 0);
+// blur (7x7, sigma 2) of the window a keypoint's descriptor reads + rotated BRIEF, from the UNBLURRED pyramid: one wave per keypoint
+hipError_t launch_brief_patch(const uint8_t* pyr_img, const OrbPyramid& pyr, const OrbFinalKeypoint* kps, int n, const Gauss7& k,
+                              uint8_t* desc, hipStream_t s, size_t pyr_stride);
 // n_sets train sets against one query set; set k = rows [k * train_stride, k * train_stride + train_counts[k])
 hipError_t launch_knn2_hamming(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out, hipStream_t s,
                                int n_sets = 1, const int* train_counts = nullptr, size_t train_stride = 0);

@@ -77,7 +77,7 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
 void stk_destroy(stk_ctx* ctx) {
     if (!ctx) return;
     multi_destroy(ctx);                    // the other devices' contexts, RCCL communicators
-    if (ctx->lane1) { stk_destroy(ctx->lane1); ctx->lane1 = nullptr; }
+    for (stk_ctx*& h : ctx->lanes) if (h) { stk_destroy(h); h = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->frames, &ctx->ref, &ctx->blur_tmp, &ctx->templates, &ctx->slots, &ctx->queue, &ctx->results,
@@ -141,7 +141,8 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ecc_ring_lookahead") { if (value < 1 || value > 5) return fail(ctx, STK_INVALID_PARAMS, "ecc_ring_lookahead must be 1..5"); ctx->opt_ecc_ring_lookahead = (int)value; }
     else if (n == "ecc_variant") { if (value != 0 && value != 3) return fail(ctx, STK_INVALID_PARAMS, "ecc_variant must be 3 (production) or 0 (direct cross-check)"); ctx->opt_ecc_variant = (int)value; }
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
-    else if (n == "kp_lanes") { if (value < 1 || value > 2) return fail(ctx, STK_INVALID_PARAMS, "kp_lanes must be 1 or 2"); ctx->opt_kp_lanes = (int)value; }
+    else if (n == "kp_lanes") { if (value < 1 || value > STK_MAX_KP_LANES) return fail(ctx, STK_INVALID_PARAMS, "kp_lanes must be 1..8"); ctx->opt_kp_lanes = (int)value; }
+    else if (n == "orb_patch_blur") ctx->opt_orb_patch_blur = value != 0;
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
     else if (n == "warp_tune") ctx->opt_warp_tune = (int)value;
     else if (n == "prep_stream") ctx->opt_prep_stream = value != 0;
@@ -392,12 +393,12 @@ stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w,
     return STK_OK;
 }
 
-// the fold launch itself over the n_frames entries of ctx->warpframes (device memory); asynchronous
+// the fold launch itself over entries [first_frame, first_frame + n_frames) of ctx->warpframes (device memory); asynchronous
 stk_status warp_fold_enqueue(stk_ctx* ctx, int n_frames, int depth, int w, int h, int cn, size_t src_row_bytes, double alpha,
                              int border_mode, const double* border_value, int is_affine, float* acc, size_t acc_stride_floats,
-                             int accumulate) {
+                             int accumulate, int first_frame) {
     WarpArgs a{};
-    a.frames = ctx->warpframes.as<WarpFrame>();
+    a.frames = ctx->warpframes.as<WarpFrame>() + first_frame;
     a.n_frames = n_frames;
     a.sw = w; a.sh = h; a.cn = cn;
     a.src_stride = src_row_bytes / (depth / 8);

@@ -62,6 +62,15 @@ def test_knn2_hamming_bit_exact(stacker):
     assert np.array_equal(one, oracle.bf_knn2_hamming(q[:4], t[:1])) and (one[:, 2] == -1).all()
     none = stacker.bf_knn2_hamming(q[:4], t[:0])
     assert (none[:, 0] == -1).all()
+    # the scan is split over eight lanes per query (rows t = lane mod 8) and merged: every train count around the split, with
+    # many exact ties (few distinct rows), must give the sequential scan's (best, second) — ties to the lower train index
+    few = rng.integers(0, 256, (3, 32), dtype=np.uint8)
+    for nt in (1, 2, 3, 7, 8, 9, 15, 16, 17, 63, 64, 65, 500):
+        tt = few[rng.integers(0, 3, nt)]
+        qq = np.concatenate([few, q[:13]])
+        assert np.array_equal(stacker.bf_knn2_hamming(qq, tt), oracle.bf_knn2_hamming(qq, tt)), nt
+    with pytest.raises(Exception):
+        stacker.bf_knn2_hamming(q[:2], np.zeros((65537, 32), np.uint8))
 
 
 def test_find_homography_known_answers(stacker):
@@ -246,18 +255,20 @@ def test_orb_tile_boundaries_bit_exact(stacker, shape):
 
 
 def test_keypoint_lanes_do_not_change_results(stacker):
-    """Device-resident stacks of >= 16 frames run as two halves side by side (kp_lanes = 2: the second half on a hidden helper
-    context of the same device, so that one half's kernels fill the other half's host steps). Frames are independent of
-    each other (lib.rs:185-290 is a Rayon map body): status, keypoint / match / inlier counts, H and the stacked image must
-    not depend on the lanes, including a frame that is dropped and repeated calls on the same context."""
+    """Device-resident stacks of >= 16 frames are cut into kp_lanes runs of >= 8 frames that go through the pipeline side by
+    side (helper contexts of the same device), and the fold follows them run by run in stack order. Frames are independent
+    of each other (lib.rs:185-290 is a Rayon map body): status, keypoint / match / inlier counts, H and the stacked image —
+    bit for bit, the fold accumulates in stack order whatever the cut — must not depend on the lanes, including a frame
+    that is dropped and repeated calls on the same context."""
     import torch
     from libstacker_rs_amd import KeyPointMatchParameters, RANSAC, synth
-    frames, _ = synth.make_stack(21, 640, 480, device="cuda")
-    frames[13] = 128                                        # a featureless frame in the second lane: dropped there
+    frames, _ = synth.make_stack(35, 640, 480, device="cuda")
+    frames[13] = 128                                        # featureless frames in two different lanes: dropped there
+    frames[30] = 7
     kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
     res = {}
     try:
-        for lanes in (2, 1, 2):
+        for lanes in (4, 1, 3, 2, 4):
             stacker.set_option("kp_lanes", lanes)
             d, out, stats = stacker.keypoint_match(frames, kp, return_stats=True)
             cur = (d, out.cpu().numpy(), [(s["status"], s["n_keypoints"], s["n_matches"], s["n_inliers"]) for s in stats],
@@ -266,17 +277,50 @@ def test_keypoint_lanes_do_not_change_results(stacker):
                 assert cur[0] == res[lanes][0] and np.array_equal(cur[1], res[lanes][1]) and cur[2] == res[lanes][2]
             res[lanes] = cur
     finally:
-        stacker.set_option("kp_lanes", 2)
-    assert res[2][0] == res[1][0] == 1
-    assert res[2][2] == res[1][2] and np.array_equal(res[2][3], res[1][3])
-    assert np.array_equal(res[2][1], res[1][1])
-    # the scale-down variant (ORB on INTER_AREA-shrunk greys, lib.rs:355-601) through both lanes as well
+        stacker.set_option("kp_lanes", 4)
+    assert res[1][0] == 2
+    for lanes in (2, 3, 4):
+        assert res[lanes][0] == res[1][0] and res[lanes][2] == res[1][2] and np.array_equal(res[lanes][3], res[1][3])
+        assert np.array_equal(res[lanes][1], res[1][1])
+    # the scale-down variant (ORB on INTER_AREA-shrunk greys, lib.rs:355-601) through the lanes as well
     outs = []
     try:
-        for lanes in (2, 1):
+        for lanes in (4, 1):
             stacker.set_option("kp_lanes", lanes)
             d, out, stats = stacker.keypoint_match(frames, kp, scale_down_width=400.0, return_stats=True)
             outs.append((d, out.cpu().numpy(), np.stack([s["warp"] for s in stats])))
     finally:
-        stacker.set_option("kp_lanes", 2)
+        stacker.set_option("kp_lanes", 4)
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
+    with pytest.raises(Exception):
+        stacker.set_option("kp_lanes", 9)
+
+
+def test_orb_patch_blur_equals_the_whole_level_blur(stacker):
+    """The descriptor kernel blurs (GaussianBlur 7x7 sigma 2, orb.cpp's fixed per-pixel operation order) only the 45 x 40 window
+    around each kept keypoint (orb_patch_blur = 1, the default); blurring every level whole first (0) must give the same
+    keypoints and descriptor bytes — single images of awkward sizes, and a stack through keypoint_match."""
+    from libstacker_rs_amd import KeyPointMatchParameters, RANSAC, synth
+    rng = np.random.default_rng(77)
+    imgs = []
+    for (h, w) in [(480, 640), (301, 517), (200, 129), (1080, 1920)]:
+        yy, xx = np.mgrid[0:h, 0:w]
+        g = ((np.sin(xx * 0.13) + np.cos(yy * 0.11) + np.sin((xx + yy) * 0.07)) * 40 + 128)
+        imgs.append(np.clip(g + rng.integers(-25, 26, g.shape), 0, 255).astype(np.uint8))
+    frames, _ = synth.make_stack(17, 640, 480, device="cuda")
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    got = {}
+    try:
+        for mode in (1, 0):
+            stacker.set_option("orb_patch_blur", mode)
+            single = [stacker.orb_detect_and_compute(g, 4096) for g in imgs]
+            d, out, stats = stacker.keypoint_match(frames, kp, return_stats=True)
+            got[mode] = (single, d, out.cpu().numpy(), np.stack([s["warp"] for s in stats]))
+    finally:
+        stacker.set_option("orb_patch_blur", 1)
+    for (k1, d1), (k0, d0) in zip(got[1][0], got[0][0]):
+        assert len(k1) > 20 and np.array_equal(k1, k0) and np.array_equal(d1, d0)
+    assert got[1][1] == got[0][1] and np.array_equal(got[1][3], got[0][3]) and np.array_equal(got[1][2], got[0][2])
+    # and against the oracle (whole-level blur, oracle_orb.cpp:102), on the 1080p image
+    ko, do = oracle.orb_detect_and_compute(imgs[3])
+    assert np.array_equal(got[1][0][3][0], ko) and np.array_equal(got[1][0][3][1], do)
