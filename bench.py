@@ -240,6 +240,22 @@ def main() -> None:
             sample = {k: t[k] for k in ("ecc_iter_ms", "ecc_iter_timed", "ecc_iter_launches", "ecc_slot_iterations")}
         finally:
             st.set_option("profile", 1)
+    # ---- keypoint / hybrid: ONE step as a single pipeline (kp_lanes = 1), so that the stage timers of FAST and of the fold
+    # bracket those kernels alone: in the timed steps the lanes' launches overlap one another, and a per-lane event pair
+    # then measures a kernel that shares the device (its bytes / its time would overstate the rate) ----
+    kp_sample = None
+    if rank == 0 and api in ("keypoint", "hybrid") and args.profile_launches > 0:
+        lanes_cfg = 4
+        for kv in args.opt:
+            if kv.split("=", 1)[0] == "kp_lanes":
+                lanes_cfg = int(kv.split("=", 1)[1])
+        st.set_option("kp_lanes", 1)
+        try:
+            run_shard(frames, accs[0])
+            t = st.timing()
+            kp_sample = {k: t[k] for k in ("fast_ms", "fast_pixels", "fast_launches", "warp_ms", "warp_frames", "warp_launches")}
+        finally:
+            st.set_option("kp_lanes", lanes_cfg)
     # ---- and what a plain float4 stream achieves on this card in this run: the 1/n scale kernel (read 4 B + write 4 B per
     # float of a W x H x 3 image), best of 5 by its own HIP-event timer ----
     stream_gbs = None
@@ -288,14 +304,19 @@ def main() -> None:
                 "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
             kernels.append({"kernel": "ecc_iter_col_kernel<homography>", "bytes": "16 B/px/frame-iteration (algorithmic; cache-served in part)",
                             "GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(avg_ms * launches, 3)})
-        if agg["warp_ms"] > 0:
+        # fold and FAST: from the single-pipeline sample step where there is one (keypoint, hybrid), else from the timed steps
+        wsrc = kp_sample if kp_sample is not None else dict(agg, **{"_steps": args.steps})
+        wsteps = 1 if kp_sample is not None else args.steps
+        alone = "one extra single-pipeline step (kp_lanes = 1) after the timed region" if kp_sample is not None else "stage timers of the timed steps"
+        if wsrc["warp_ms"] > 0:
             # fused fold: every frame's source read once + the accumulator written once per launch (no read: the launch
             # overwrites); SURVEY 8d's per-frame figure (source + accumulator read + write for EVERY frame) is the unfused cost
-            wb = agg["warp_frames"] * src_b + agg["warp_launches"] * 12 * px
-            g = wb / agg["warp_ms"] / 1e6
+            wb = wsrc["warp_frames"] * src_b + wsrc["warp_launches"] * 12 * px
+            g = wb / wsrc["warp_ms"] / 1e6
             kernels.append({"kernel": "warp_accumulate_%s" % ("u16c3" if depth == 16 else "u8c3"),
                             "bytes": "frames x %d B/px source + 12 B/px accumulator write per launch" % (src_b // px),
-                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(agg["warp_ms"] / args.steps, 3)})
+                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(wsrc["warp_ms"] / wsteps, 3),
+                            "timing": alone})
         if api == "ecc" and world == 1:
             # template preparation: in the timed steps it runs on the prep stream under the iteration of the first frames
             # (its time is inside align_ms); its own stage timer needs a step with the overlap switched off, outside the
@@ -312,18 +333,19 @@ def main() -> None:
                             "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(prep_ms, 3),
                             "note": "one extra step with prep_overlap = 0 (not in the timed region); in the timed steps this runs "
                                     "under the ECC iteration of the first frames"})
-        if agg["fast_ms"] > 0:
+        if wsrc["fast_ms"] > 0:
             # FAST-9/16 + NMS + Harris short list over the 8 pyramid levels: reads each level's u8 pixels once
-            g = agg["fast_pixels"] / agg["fast_ms"] / 1e6
-            kernels.append({"kernel": "fast_nms_tiled_kernel (8 level launches per batch)", "bytes": "1 B/px of every pyramid level",
-                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(agg["fast_ms"] / args.steps, 3),
-                            "limiter": "integer VALU (ring tests)"})
+            g = wsrc["fast_pixels"] / wsrc["fast_ms"] / 1e6
+            kernels.append({"kernel": "fast_nms_tiled_all_kernel + threshold + pick + describe (all 8 levels, one launch each per batch)",
+                            "bytes": "1 B/px of every pyramid level",
+                            "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "ms_per_step": round(wsrc["fast_ms"] / wsteps, 3),
+                            "limiter": "integer VALU (ring tests)", "timing": alone})
         if api == "keypoint" and kernels:
             k = kernels[-1]
             res["roofline"] = {"kernel": k["kernel"], "bound": "hbm", "limiter": "valu-issue", "achieved": k["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": k["frac"], "traffic": None,
                                "peak_achievable": round(stream_gbs, 1) if stream_gbs else None,
-                               "timing": "HIP events around the 8 level launches of every ORB batch, engine stream"}
+                               "timing": "HIP events around the FAST launches of every ORB batch, engine stream; " + alone}
         res["kernels"] = kernels
         its = [s["iterations"] for s in (last_stats or [])[1:]]
         res["stages"] = {

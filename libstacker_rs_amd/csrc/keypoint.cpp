@@ -125,20 +125,6 @@ void orb_geometry(int w, int h, OrbGeometry& g) {
     for (int i = 0; i < 7; i++) g.g7.k[i] = (float)(kd[i] * (1.0 / ks));
 }
 
-// KeyPointsFilter::retainBest: keep everything with response >= the n-th best
-template <typename T, typename F>
-void retain_best(std::vector<T>& v, int n, F resp) {
-    if (n < 0 || (int)v.size() <= n) return;
-    if (n == 0) { v.clear(); return; }
-    std::vector<float> r(v.size());
-    for (size_t i = 0; i < v.size(); i++) r[i] = resp(v[i]);
-    std::nth_element(r.begin(), r.begin() + (n - 1), r.end(), std::greater<float>());
-    const float thr = r[n - 1];
-    std::vector<T> o;
-    for (auto& k : v) if (resp(k) >= thr) o.push_back(k);
-    v.swap(o);
-}
-
 constexpr size_t MAX_KP = 4096;   // descriptor rows per frame (500 + ties)
 constexpr int ORB_PACK = 512;     // short-list entries per level fetched in the one strided copy (2 n_l + ties fit; else a 2nd copy)
 
@@ -268,29 +254,44 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     parallel_for(ctx, n_frames, threads, [&](int f) {
         std::vector<HostKeypoint>& o = out[f];
         std::vector<OrbFinalKeypoint>& fin = fins[f];
+        size_t n_short = 0;
+        for (int l = 0; l < ORB_LEVELS; l++) n_short += (size_t)ws->host_states[f * ORB_LEVELS + l].n_sel;
+        o.reserve(n_short); fin.reserve(n_short);            // (the cull keeps about half: one allocation each instead of ten)
+        std::vector<OrbSelected> v;
+        std::vector<float> resp;
         for (int l = 0; l < ORB_LEVELS; l++) {
             const int n = ws->host_states[f * ORB_LEVELS + l].n_sel;
             const auto& bv = big[(size_t)f * ORB_LEVELS + l];
             const OrbSelected* src = n > ORB_PACK ? bv.data() : ws->host_sel + ((size_t)f * ORB_LEVELS + l) * ORB_PACK;
-            std::vector<OrbSelected> v(src, src + n);
-            // cull to n_l by the Harris response (ties kept), then a deterministic order
-            retain_best(v, g.nfeatures[l], [](const OrbSelected& k) { return k.harris; });
+            // cull to n_l by the Harris response (KeyPointsFilter::retainBest: everything >= the n_l-th best stays, ties
+            // included), then a deterministic order
+            const int keep = g.nfeatures[l];
+            float thr = -FLT_MAX;
+            if (keep == 0) thr = FLT_MAX;
+            else if (keep > 0 && n > keep) {
+                resp.resize(n);
+                for (int i = 0; i < n; i++) resp[i] = src[i].harris;
+                std::nth_element(resp.begin(), resp.begin() + (keep - 1), resp.end(), std::greater<float>());
+                thr = resp[keep - 1];
+            }
+            v.clear();
+            for (int i = 0; i < n; i++) if (keep != 0 && src[i].harris >= thr) v.push_back(src[i]);
             std::sort(v.begin(), v.end(), [](const OrbSelected& p, const OrbSelected& q) {
                 if (p.harris != q.harris) return p.harris > q.harris;
                 const int py = p.xy >> 16, qy = q.xy >> 16;
                 if (py != qy) return py < qy;
                 return (p.xy & 0xffff) < (q.xy & 0xffff);
             });
+            const float sc = g.scale[l], inv = 1.f / sc, size = 31 * sc;
             for (const OrbSelected& k : v) {
                 HostKeypoint hk;
                 hk.lx = k.xy & 0xffff; hk.ly = k.xy >> 16; hk.octave = l;
                 hk.response = k.harris;
                 hk.angle = fast_atan2((float)k.m01, (float)k.m10);
-                hk.size = 31 * g.scale[l];
-                hk.x = (float)hk.lx * g.scale[l]; hk.y = (float)hk.ly * g.scale[l];
+                hk.size = size;
+                hk.x = (float)hk.lx * sc; hk.y = (float)hk.ly * sc;
                 o.push_back(hk);
                 // computeOrbDescriptors: centre = cvRound(pt * (1/scale)), a = cos(angle deg->rad), b = sin
-                const float inv = 1.f / g.scale[l];
                 float ang = hk.angle;
                 ang *= (float)(3.14159265358979323846 / 180.f);
                 OrbFinalKeypoint fk;
@@ -525,14 +526,15 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } ref_ev_guard{ref.ev};
 
     const bool two_lanes_cfg = ctx->opt_kp_lanes >= 2 && !host_fed && n >= 16;
+    const int n_lanes = two_lanes_cfg ? std::max(2, std::min({ctx->opt_kp_lanes, STK_MAX_KP_LANES, n / 8})) : 1;
     // one lane: frames [lo, hi) of the stack through ORB -> 2-NN -> match filter -> findHomography on context `c`
     auto run_lane = [&](stk_ctx* c, int lo, int hi) -> stk_status {
         stk_status st;
         (void)hipSetDevice(c->device);
         const int cnt = hi - lo;
-        // frames per ORB batch: the whole lane when it fits a 32 GiB workspace (it does for every BASELINE config but the
-        // 1024-frame one), else chunks
-        int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, ((size_t)32 << 30) / orb_bytes_per_frame(g)));
+        // frames per ORB batch: the whole lane when it fits its share of a 32 GiB workspace — all lanes together, the helper
+        // contexts' workspaces add up (it does for every BASELINE config but the 1024-frame one) — else chunks
+        int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, (((size_t)32 << 30) / (size_t)n_lanes) / orb_bytes_per_frame(g)));
         batch = (cnt + (cnt + batch - 1) / batch - 1) / ((cnt + batch - 1) / batch);     // even batches: 256 frames as 128 + 128, not 245 + 11
         if (host_fed) batch = std::min(batch, 1 + c->opt_upload_batch);      // measured at 64 x 1080p: 9-frame ORB batches 11.4 ms, 17: 12.8, 65: 15.3
         if ((st = orb_prepare(c, c->kp, ew, eh, g, batch))) return st;
@@ -671,7 +673,6 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     };
 
     // lane 0 always (the calling thread); helper lanes for device-resident stacks large enough to be worth more pipelines
-    const int n_lanes = two_lanes_cfg ? std::max(2, std::min({ctx->opt_kp_lanes, STK_MAX_KP_LANES, n / 8})) : 1;
     std::vector<int> cut(n_lanes + 1);
     for (int k = 0; k <= n_lanes; k++) cut[k] = (int)(((int64_t)n * k + n_lanes - 1) / n_lanes);
     std::vector<stk_status> lane_st(n_lanes, STK_OK);
