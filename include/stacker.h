@@ -181,6 +181,8 @@ void        stk_host_free(void* p);
  *                        least 8 each) that go through the pipeline side by side, the later ones on hidden helper contexts of
  *                        the same device, so that one run's kernels fill the other runs' host steps; the fold follows run by
  *                        run in stack order. 1: one pipeline. Per-frame results and the stacked image do not depend on it
+ *   "orb_resize_tables"  1 (default): ORB's pyramid steps read their bilinear coefficient tables from memory (computed once per
+ *                        geometry); 0: every tile computes its own. Same bits either way
  *   "orb_patch_blur"     1 (default): ORB's 7x7 blur is computed by the descriptor kernel, for the 45 x 40 window around each kept
  *                        keypoint only; 0: every pyramid level is blurred whole first. Same bits either way
  *   "kp_workers"         host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)

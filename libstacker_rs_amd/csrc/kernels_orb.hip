@@ -24,9 +24,8 @@ __device__ __forceinline__ int refl101(int p, int len) {
 
 // four bytes at any address through aligned dword loads (level rows are not dword-aligned in general)
 __device__ __forceinline__ uint32_t load4_unaligned(const uint8_t* p) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh);   // pointer arithmetic keeps the address space: global_load, not flat_load
     const uint32_t lo = q[0];
     if (sh == 0) return lo;
     return __builtin_amdgcn_alignbyte(q[1], lo, sh);   // bytes sh .. sh+3 of the aligned pair
@@ -155,8 +154,99 @@ __global__ __launch_bounds__(256) void resize_exact_tiled_kernel(const uint8_t* 
     }
 }
 
+// Round 3: the pyramid step without a tile. The tiled kernel above is neither VALU- nor HBM-bound (SQ counters: 6 waves per
+// SIMD that each live 7 us): table computation in f64 by 160 threads while the others wait, a staged footprint behind a
+// barrier, four LDS byte reads per pixel. A first rewrite that kept the tile but read its tables from memory cut the VALU
+// count by 40 % and the time by nothing. This one has no LDS and no barrier: a thread makes 4 adjacent pixels of 4 rows; the
+// step's tables — (offset | weight << 16) of every column and row, a function of the level sizes only, computed once per
+// geometry by resize_tables_kernel with the same f64 lin_coef — give it the first column's source offset; the six source
+// bytes its four columns touch in a row (3 steps of <= 1.3 px, + the right-hand tap) come with ONE aligned 12-byte load + v_alignbyte,
+// a 64-bit shift per pixel extracts the two taps. A tap the reference clamps (last column / row) has weight 0 or is
+// clamped here too (rows), so whatever byte sits behind the row's end is never used. Same integer arithmetic, bit-identical
+// (test_orb_table_driven_pyramid_equals_the_per_tile_tables); the final min(., 255) is dropped: the weights of a pixel
+// sum to 65536, so (v + 32768) >> 16 <= 255.
+__global__ void resize_tables_kernel(int sw, int sh, int dw, int dh, double scale_x, double scale_y, int* __restrict__ xt, int* __restrict__ yt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int o, c0, c1;
+    if (i < ((dw + 3) & ~3)) { lin_coef(min(i, dw - 1), sw, scale_x, o, c0, c1); xt[i] = o | (c1 << 16); }    // padded to whole quads
+    if (i < ((dh + 3) & ~3)) { lin_coef(min(i, dh - 1), sh, scale_y, o, c0, c1); yt[i] = o | (c1 << 16); }
+}
+
+// eight bytes at any address: the three aligned dwords that hold them (ONE 12-byte load: an unaligned 8-byte load costs the
+// L1 tag pipeline ~46 look-ups per wave instruction, measured — TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD) and two v_alignbyte
+struct Dw3 { uint32_t a, b, c; };
+__device__ __forceinline__ unsigned long long load8_at(const uint8_t* p) {
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+    const Dw3 t = *reinterpret_cast<const Dw3*>(p - sh);          // (pointer arithmetic, not an integer round trip: stays a global load)
+    const uint32_t lo = __builtin_amdgcn_alignbyte(t.b, t.a, sh), hi = __builtin_amdgcn_alignbyte(t.c, t.b, sh);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void resize_exact_direct_kernel(const uint8_t* __restrict__ src, int sw, int sh,
+                                                                  uint8_t* __restrict__ dst, int dw, int dh,
+                                                                  const int4* __restrict__ xt, const int4* __restrict__ yt, size_t frame_stride) {
+    const int xq = blockIdx.x * 64 + (threadIdx.x & 63), yq = blockIdx.y * 4 + (threadIdx.x >> 6);     // quad column, quad row
+    const int x = 4 * xq, y = 4 * yq;
+    if (x >= dw || y >= dh) return;
+    src += blockIdx.z * frame_stride; dst += blockIdx.z * frame_stride;
+    const int4 xv = xt[xq], yv = yt[yq];
+    const int xo[4] = {xv.x & 0xffff, xv.y & 0xffff, xv.z & 0xffff, xv.w & 0xffff};
+    const uint32_t xc[4] = {(uint32_t)xv.x >> 16, (uint32_t)xv.y >> 16, (uint32_t)xv.z >> 16, (uint32_t)xv.w >> 16};
+    const int yo[4] = {yv.x & 0xffff, yv.y & 0xffff, yv.z & 0xffff, yv.w & 0xffff};
+    const uint32_t yc[4] = {(uint32_t)yv.x >> 16, (uint32_t)yv.y >> 16, (uint32_t)yv.z >> 16, (uint32_t)yv.w >> 16};
+    const int base = xo[0];
+    const uint32_t sft[4] = {0u, (uint32_t)(xo[1] - base) * 8u, (uint32_t)(xo[2] - base) * 8u, (uint32_t)(xo[3] - base) * 8u};
+    const bool aligned = (dw & 3) == 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (y + k >= dh) break;
+        const uint8_t* r0 = src + (size_t)yo[k] * sw + base;
+        const uint8_t* r1 = src + (size_t)min(yo[k] + 1, sh - 1) * sw + base;
+        const unsigned long long w0 = load8_at(r0), w1 = load8_at(r1);
+        const uint32_t cy1 = yc[k], cy0 = 256u - cy1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t cx1 = xc[e], cx0 = 256u - cx1;
+            const uint32_t t0 = (uint32_t)(w0 >> sft[e]), t1 = (uint32_t)(w1 >> sft[e]);
+            const uint32_t h0 = cx0 * (t0 & 255u) + cx1 * ((t0 >> 8) & 255u);
+            const uint32_t h1 = cx0 * (t1 & 255u) + cx1 * ((t1 >> 8) & 255u);
+            const uint32_t v = cy0 * h0 + cy1 * h1 + (1u << 15);
+            out |= (v >> 16) << (8 * e);
+        }
+        uint8_t* op = dst + (size_t)(y + k) * dw + x;
+        if (aligned && x + 3 < dw) *reinterpret_cast<uint32_t*>(op) = out;
+        else {
+            op[0] = (uint8_t)out;
+            if (x + 1 < dw) op[1] = (uint8_t)(out >> 8);
+            if (x + 2 < dw) op[2] = (uint8_t)(out >> 16);
+            if (x + 3 < dw) op[3] = (uint8_t)(out >> 24);
+        }
+    }
+}
+
+// tables of one pyramid step at `tab` (16-byte aligned): ((dw + 3) & ~3) column entries, then ((dh + 3) & ~3) row entries
+size_t resize_tables_ints(int dw, int dh) { return (size_t)((dw + 3) & ~3) + (size_t)((dh + 3) & ~3); }
+hipError_t launch_resize_tables(int sw, int sh, int dw, int dh, int* tab, hipStream_t s) {
+    const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
+    const int n = std::max((dw + 3) & ~3, (dh + 3) & ~3);
+    resize_tables_kernel<<<(n + 255) / 256, 256, 0, s>>>(sw, sh, dw, dh, sx, sy, tab, tab + ((dw + 3) & ~3));
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s,
-                               int n_frames, size_t frame_stride) {
+                               int n_frames, size_t frame_stride, const int* tab) {
+    if (tab) {
+        // the 12-byte window of a row may run past the row's end by up to 11 bytes (never used): the caller's buffer must have that
+        // slack behind the last row (the pyramid workspace has 64 bytes); offsets and weights share a 32-bit table entry
+        const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
+        if (sw >= 2 && sh >= 2 && sw < 65536 && sh < 65536 && sx <= 1.3 && sy <= 1.3 && (reinterpret_cast<uintptr_t>(tab) & 15) == 0) {
+            dim3 grid(((dw + 3) / 4 + 63) / 64, ((dh + 3) / 4 + 3) / 4, n_frames);
+            resize_exact_direct_kernel<<<grid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, reinterpret_cast<const int4*>(tab),
+                                                            reinterpret_cast<const int4*>(tab + ((dw + 3) & ~3)), frame_stride);
+            return hipGetLastError();
+        }
+    }
     const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
     if (sw >= 8 && sh >= 2 && sx <= 1.3 && sy <= 1.3 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (frame_stride & 3) == 0) {
         dim3 tgrid((dw + RT_X - 1) / RT_X, (dh + RT_Y - 1) / RT_Y, n_frames);

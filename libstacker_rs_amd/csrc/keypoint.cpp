@@ -39,8 +39,10 @@ using namespace stk;
 namespace stk {
 
 struct KeypointWorkspace {
-    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn, gfull, counts;
+    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn, gfull, counts, rtab;
     bool pattern_uploaded = false;
+    int rtab_w = 0, rtab_h = 0;             // level-0 size the resize tables in `rtab` were computed for
+    size_t rtab_ofs[ORB_LEVELS] = {};       // ints into rtab: tables of the step level l - 1 -> l
     OrbSelected* host_sel = nullptr;        // pinned: [frames][ORB_LEVELS][ORB_PACK] head of every short list
     OrbLevelState* host_states = nullptr;   // pinned: [frames][ORB_LEVELS]
     OrbFinalKeypoint* host_final = nullptr; // pinned: the kept keypoints of a batch, back to back (read by an async copy)
@@ -52,7 +54,7 @@ struct KeypointWorkspace {
 KeypointWorkspace* keypoint_workspace_create() { return new KeypointWorkspace(); }
 void keypoint_workspace_destroy(KeypointWorkspace* k) {
     if (!k) return;
-    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn, &k->gfull, &k->counts})
+    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn, &k->gfull, &k->counts, &k->rtab})
         b->release();
     if (k->host_sel) (void)hipHostFree(k->host_sel);
     if (k->host_states) (void)hipHostFree(k->host_states);
@@ -175,7 +177,7 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     HIP_TRY(hipMemsetAsync(st, 0, sizeof(OrbLevelState) * ORB_LEVELS * n_frames, s));
     for (int l = 1; l < ORB_LEVELS; l++)
         HIP_TRY(launch_resize_exact(pyr + g.pyr.ofs[l - 1], g.pyr.w[l - 1], g.pyr.h[l - 1], pyr + g.pyr.ofs[l], g.pyr.w[l], g.pyr.h[l], s,
-                                    n_frames, PT));
+                                    n_frames, PT, ctx->opt_orb_resize_tables ? ws->rtab.as<int>() + ws->rtab_ofs[l] : nullptr));
     const bool timed = ctx->opt_profile >= 1;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[6], s));
     // FAST + NMS + short list: all levels in four launches when every level qualifies for the tiled kernel, else level by level
@@ -341,6 +343,15 @@ stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeo
         HIP_TRY(hipHostMalloc((void**)&ws->host_sel, sizeof(OrbSelected) * ORB_PACK * ORB_LEVELS * F, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&ws->host_states, sizeof(OrbLevelState) * ORB_LEVELS * F, hipHostMallocDefault));
         ws->host_frames_cap = F;
+    }
+    // coefficient tables of the seven pyramid steps: a function of the level sizes only
+    if (ws->rtab_w != w || ws->rtab_h != h) {
+        size_t n_int = 0;
+        for (int l = 1; l < ORB_LEVELS; l++) { ws->rtab_ofs[l] = n_int; n_int += resize_tables_ints(g.pyr.w[l], g.pyr.h[l]); }
+        HIP_TRY(ws->rtab.reserve(sizeof(int) * n_int));
+        for (int l = 1; l < ORB_LEVELS; l++)
+            HIP_TRY(launch_resize_tables(g.pyr.w[l - 1], g.pyr.h[l - 1], g.pyr.w[l], g.pyr.h[l], ws->rtab.as<int>() + ws->rtab_ofs[l], ctx->stream));
+        ws->rtab_w = w; ws->rtab_h = h;
     }
     // the BRIEF pattern lives in __constant__ memory of the module: uploaded once
     if (!ws->pattern_uploaded) { HIP_TRY(upload_orb_pattern(ORB_BIT_PATTERN_31)); ws->pattern_uploaded = true; }
@@ -715,7 +726,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 if ((st = stk_create(ctx->device, &hk))) return fail(ctx, st, "keypoint lane: helper context creation failed");
                 (void)hipSetDevice(ctx->device);
             }
-            hk->opt_kp_workers = ctx->opt_kp_workers; hk->opt_orb_patch_blur = ctx->opt_orb_patch_blur; hk->opt_profile = ctx->opt_profile;
+            hk->opt_kp_workers = ctx->opt_kp_workers; hk->opt_orb_patch_blur = ctx->opt_orb_patch_blur; hk->opt_orb_resize_tables = ctx->opt_orb_resize_tables; hk->opt_profile = ctx->opt_profile;
             hk->opt_upload_batch = ctx->opt_upload_batch;
             timing_begin(hk);
             if (threads > 1) hk->shared_pool = ctx->shared_pool ? ctx->shared_pool : ctx->host_pool;

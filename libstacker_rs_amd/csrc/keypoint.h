@@ -32,8 +32,12 @@ KeypointWorkspace* keypoint_workspace_create();
 void keypoint_workspace_destroy(KeypointWorkspace*);
 
 // The ORB launchers are batched over frames: n_frames images whose per-frame arrays sit `*_stride` elements apart.
+// `tab`: the step's coefficient tables (launch_resize_tables: resize_tables_ints(dw, dh) ints, 16-byte aligned) — then `src` needs 11
+// readable bytes behind its last row —, or null (tables computed per tile)
 hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s,
-                               int n_frames = 1, size_t frame_stride = 0);
+                               int n_frames = 1, size_t frame_stride = 0, const int* tab = nullptr);
+hipError_t launch_resize_tables(int sw, int sh, int dw, int dh, int* tab, hipStream_t s);
+size_t resize_tables_ints(int dw, int dh);
 hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s);
 // scale_image's target size (utils.rs:186-214): the SMALLER dimension becomes scale_down, `as i32` truncation
 inline bool scaled_size(int w, int h, float scale_down, int& nw, int& nh) {

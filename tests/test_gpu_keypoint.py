@@ -324,3 +324,27 @@ def test_orb_patch_blur_equals_the_whole_level_blur(stacker):
     # and against the oracle (whole-level blur, oracle_orb.cpp:102), on the 1080p image
     ko, do = oracle.orb_detect_and_compute(imgs[3])
     assert np.array_equal(got[1][0][3][0], ko) and np.array_equal(got[1][0][3][1], do)
+
+
+def test_orb_table_driven_pyramid_equals_the_per_tile_tables(stacker):
+    """The pyramid steps read offset / weight tables computed once per geometry (orb_resize_tables = 1, the default) and stage
+    the source footprint with one replicated column / row behind the image; computing the tables per tile (0, round 2's
+    kernel) must give the same keypoints and descriptors — widths and heights around the tile and 16-byte boundaries."""
+    rng = np.random.default_rng(5)
+    got = {}
+    imgs = [rng.integers(0, 256, (h, w), dtype=np.uint8) for (h, w) in [(480, 640), (301, 517), (200, 129), (95, 1000), (1080, 1920), (130, 131)]]
+    imgs = [np.clip(np.kron(rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8)), np.ones((8, 8)))[:h, :w] * 0.7 + im * 0.3, 0, 255).astype(np.uint8)
+            for im, (h, w) in zip(imgs, [i.shape for i in imgs])]
+    try:
+        for mode in (1, 0):
+            stacker.set_option("orb_resize_tables", mode)
+            got[mode] = [stacker.orb_detect_and_compute(g, 4096) for g in imgs]
+    finally:
+        stacker.set_option("orb_resize_tables", 1)
+    n_total = 0
+    for (k1, d1), (k0, d0) in zip(got[1], got[0]):
+        assert np.array_equal(k1, k0) and np.array_equal(d1, d0)
+        n_total += len(k1)
+    assert n_total > 500
+    ko, do = oracle.orb_detect_and_compute(imgs[1])
+    assert np.array_equal(got[1][1][0], ko) and np.array_equal(got[1][1][1], do)
