@@ -678,14 +678,31 @@ __device__ __forceinline__ void fast_describe_body(const uint8_t* __restrict__ i
             a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
         }
         a = wave_sum_i32(a); b = wave_sum_i32(b); cc = wave_sum_i32(cc);
-        // IC moments over the circular patch: lane = row v in [-15, 15]
+        // IC moments over the circular patch (integer sums: any order gives the same bits). Round 3: a lane is a COLUMN u in
+        // [-15, 16] of the upper (v = -15 .. 0) or lower (v = 1 .. 16) half of the patch; its 16 pixels are loaded
+        // unconditionally, all in flight at once (a short-listed corner is >= 31 px from every border, so the 32 x 32 block is
+        // inside the level), and masked afterwards by the disc: bit |v| of `disc` = (|u| <= umax[|v|]). Before, a lane per row
+        // walked its row alone, and a first column version looked umax up per step: either way ~30 DEPENDENT global loads per
+        // corner, 24 us per corner-wave, 200 us per 64 frames for 0.2 MB of pixels per frame.
         int m01 = 0, m10 = 0;
-        if (lane < 31) {
-            const int v = lane - 15, d = um.u[v < 0 ? -v : v];
-            const uint8_t* row = p0 + v * w;
-            int rs = 0;
-            for (int u = -d; u <= d; u++) { const int px = row[u]; m10 += u * px; rs += px; }
-            m01 = v * rs;
+        {
+            const int half = lane >> 5, u = (lane & 31) - 15;
+            const int au = u < 0 ? -u : u;
+            unsigned disc = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) disc |= (unsigned)(au <= um.u[j]) << j;
+            const uint8_t* col = p0 + (half ? w : -15 * w) + u;            // v = 1 or v = -15
+            int px[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) px[i] = col[i * w];
+            int cs = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int v = half ? i + 1 : i - 15, av = v < 0 ? -v : v;      // av = 16 (lower half's last row): outside the disc
+                const int t = (av < 16 && ((disc >> av) & 1u)) ? px[i] : 0;
+                cs += t; m01 += v * t;
+            }
+            m10 = u * cs;
         }
         m01 = wave_sum_i32(m01); m10 = wave_sum_i32(m10);
         if (lane == 0) {
