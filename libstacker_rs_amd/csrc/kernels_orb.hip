@@ -409,6 +409,7 @@ extern "C" void stk_debug_fast_timing(unsigned long long* out) { (void)hipMemcpy
 #else
 #define FAST_TICK(i) do { } while (0)
 #endif
+struct __attribute__((aligned(4))) U4a4 { uint32_t x, y, z, w; };   // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
 __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ img, int w, int h, int thr, int edge,
                                                     OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs, int tile_x, int tile_y) {
     __shared__ __attribute__((aligned(16))) uint8_t T[FT_TH * FT_TW];
@@ -421,31 +422,46 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
     FAST_TICK(0);
     if (tid == 0) { nA = 0; nB = 0; }
     {
-        // every global load of the thread is issued before the first LDS store: one memory round trip per tile instead of
-        // six in a row (the tile load was 3.3 us of a tile's 10 us, and this kernel is bound by such latencies, not by
-        // issue: waves parked half of their cycles, round 2's PMC)
-        constexpr int NIT = (FT_TH * (FT_TW / 4) + 255) / 256;
-        uint32_t v[NIT];
+        // The 136 x 40 byte tile in 16-byte pieces (9 per row, the last one half used): a piece is the five aligned dwords
+        // that hold it — one 16-byte and one 4-byte load — shifted into place by four v_alignbyte. Round 3: dword by dword
+        // (two aligned loads + a shift per dword, six per thread) the tile load was 210 of the kernel's 1 019 VALU instructions
+        // per wave, and this kernel is bound by exactly that count (rocprofv3 SQ counters with the later passes cut off:
+        // tile 210, compass pass 575, ring masks 179, strength 45, NMS 10). All global loads of a thread are issued before
+        // its first LDS store: one memory round trip per tile.
+        constexpr int PCS = 9, NIT = (FT_TH * PCS + 255) / 256;          // 360 pieces, 2 per thread
+        uint4 v[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; k++) {
-            const int i = tid + 256 * k;
-            const int ii = min(i, FT_TH * (FT_TW / 4) - 1);
-            const int ty = ii / (FT_TW / 4), d = ii - ty * (FT_TW / 4);
+            const int i = min(tid + 256 * k, FT_TH * PCS - 1);
+            const int ty = i / PCS, d = i - ty * PCS;
             const int sy = min(max(y0 - FT_H + ty, 0), h - 1);        // values outside the image are never used
-            const int sx0 = x0 - FT_H + 4 * d;
+            const int sx0 = x0 - FT_H + 16 * d;
             const uint8_t* row = img + (size_t)sy * w;
-            v[k] = 0;
-            if (sx0 >= 0 && sx0 + 3 < w) v[k] = load4_unaligned(row + sx0);
-            else {
+            if (sx0 >= 0 && sx0 + 15 < w) {
+                const uint8_t* p = row + sx0;
+                const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh);
+                const U4a4 a = *reinterpret_cast<const U4a4*>(q);
+                const uint32_t e = q[4];                               // (<= 3 bytes behind the piece: the next row, or the pyramid's slack)
+                v[k] = make_uint4(__builtin_amdgcn_alignbyte(a.y, a.x, sh), __builtin_amdgcn_alignbyte(a.z, a.y, sh),
+                                  __builtin_amdgcn_alignbyte(a.w, a.z, sh), __builtin_amdgcn_alignbyte(e, a.w, sh));
+            } else {
+                uint32_t b[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[k] |= (uint32_t)row[min(max(sx0 + e, 0), w - 1)] << (8 * e);
+                for (int e = 0; e < 16; e++) b[e >> 2] |= (uint32_t)row[min(max(sx0 + e, 0), w - 1)] << (8 * (e & 3));
+                v[k] = make_uint4(b[0], b[1], b[2], b[3]);
             }
         }
         for (int i = tid; i < FT_SH * FT_SW / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
 #pragma unroll
         for (int k = 0; k < NIT; k++) {
             const int i = tid + 256 * k;
-            if (i < FT_TH * (FT_TW / 4)) { const int ty = i / (FT_TW / 4), d = i - ty * (FT_TW / 4); *reinterpret_cast<uint32_t*>(T + ty * FT_TW + 4 * d) = v[k]; }
+            if (i < FT_TH * PCS) {
+                const int ty = i / PCS, d = i - ty * PCS;
+                uint2* t = reinterpret_cast<uint2*>(T + ty * FT_TW + 16 * d);       // rows are 8-byte aligned (136 = 17 x 8)
+                t[0] = make_uint2(v[k].x, v[k].y);
+                if (d < PCS - 1) t[1] = make_uint2(v[k].z, v[k].w);
+            }
         }
     }
     __syncthreads();
@@ -462,6 +478,8 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
         constexpr int ROW_DW = FT_TW / 4;                               // 34 dwords per tile row
         const uint32_t T2 = (uint32_t)thr | ((uint32_t)thr << 16);
         const int lane = tid & 63;
+        // a tile whose 130 x 34 score region lies inside [3, w - 3) x [3, h - 3): the validity mask depends on dq alone
+        const bool interior = x0 - 1 >= 3 && x0 + FT_X + 1 <= w - 3 && y0 - 1 >= 3 && y0 + FT_Y + 1 <= h - 3;
         for (int i0 = tid - lane; i0 < FT_SH * ROW_DW; i0 += 256) {      // wave-uniform trip count
             const int i = i0 + lane;
             const bool act = i < FT_SH * ROW_DW;
@@ -477,18 +495,21 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
             // needs (N or S) AND (E or W) beyond the threshold on the same side: a necessary condition that is tighter than
             // "two of the four" (which also admits N+S or E+W alone) and takes 3 instead of 7 logic operations per side. The
             // exact ring test of pass 2 decides either way: same corners, same bits.
+            // centre - tap > thr  <=>  tap < centre - thr: the sign of tap - lo; centre - tap < -thr  <=>  the sign of hi - tap
+            // (16-bit lanes: all operands are within [-255, 510]). One subtraction per tap and side.
             uint32_t r[2];
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const uint32_t sel = half ? 0x0c030c02u : 0x0c010c00u;   // bytes (2, 3) or (0, 1) into the low bytes of two 16-bit lanes
                 const uint32_t C = __builtin_amdgcn_perm(0u, c0, sel);
+                const uint32_t lo = pk_sub_i16(C, T2), hi = pk_add_i16(C, T2);
                 uint32_t dk[4], br[4];
                 const uint32_t taps[4] = {nn, ee, ss, ww};
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
-                    const uint32_t D = pk_sub_i16(C, __builtin_amdgcn_perm(0u, taps[d], sel));
-                    dk[d] = pk_sub_i16(T2, D);                           // sign set: centre darker-side test (D > thr)
-                    br[d] = pk_add_i16(D, T2);                           // sign set: D < -thr
+                    const uint32_t t = __builtin_amdgcn_perm(0u, taps[d], sel);
+                    dk[d] = pk_sub_i16(t, lo);                           // sign set: tap < centre - thr (centre darker-side test passes)
+                    br[d] = pk_sub_i16(hi, t);                           // sign set: tap > centre + thr
                 }
 #if STK_FAST_PRETEST == 0
                 r[half] = (((dk[0] | dk[1]) & (dk[2] | dk[3])) | (dk[0] & dk[1]) | (dk[2] & dk[3])) |
@@ -497,11 +518,17 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
                 r[half] = ((dk[0] | dk[2]) & (dk[1] | dk[3])) | ((br[0] | br[2]) & (br[1] | br[3]));
 #endif
             }
-            uint32_t m = ((r[0] >> 15) & 1u) | ((r[0] >> 30) & 2u) | ((r[1] >> 13) & 4u) | ((r[1] >> 28) & 8u);
+            // sign bits of r[0] (pixels 0, 1) and r[1] (pixels 2, 3) -> bits 0 .. 3
+            const uint32_t sg = ((r[0] & 0x80008000u) >> 15) | ((r[1] & 0x80008000u) >> 13);      // bits 0, 16 | 2, 18
+            uint32_t m = (sg | (sg >> 15)) & 0xfu;
             // pixel k of this dword: sx = 4 dq - 3 + k in [0, FT_X + 2), image x = x0 - 4 + 4 dq + k in [3, w - 3), y likewise
-            const int xq = x0 - 4 + 4 * dq, y = y0 - 1 + sy;
-            const int klo = max(max(3 - 4 * dq, 3 - xq), 0), khi = min(min(FT_X + 5 - 4 * dq, w - 3 - xq), 4);
-            const uint32_t vm = (act && y >= 3 && y < h - 3 && khi > klo) ? ((1u << khi) - 1u) & ~((1u << klo) - 1u) : 0u;
+            uint32_t vm;
+            if (interior) vm = act ? (dq == 0 ? 0x8u : dq == ROW_DW - 1 ? 0x1u : 0xfu) : 0u;          // wave-uniform branch
+            else {
+                const int xq = x0 - 4 + 4 * dq, y = y0 - 1 + sy;
+                const int klo = max(max(3 - 4 * dq, 3 - xq), 0), khi = min(min(FT_X + 5 - 4 * dq, w - 3 - xq), 4);
+                vm = (act && y >= 3 && y < h - 3 && khi > klo) ? ((1u << khi) - 1u) & ~((1u << klo) - 1u) : 0u;
+            }
             m &= vm;
             const unsigned long long b0 = __ballot(m & 1u), b1 = __ballot(m & 2u), b2 = __ballot(m & 4u), b3 = __ballot(m & 8u);
             const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
