@@ -131,11 +131,16 @@ def main() -> None:
     st.set_option("profile", 1)
     stride = max(1, args.profile_launches)
     # two accumulators: while step k's sum is being reduced over xGMI, step k+1 aligns into the other one
-    accs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
-    cnts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(len(accs))]
+    # (the two counters of a stack — frames folded, frames dropped — ride behind the accumulator in the same buffer, as floats:
+    # ONE collective per stack instead of two, one small host -> device copy instead of two scalar writes, one read-back)
+    n_acc = H * W * 3
+    flats = [torch.empty(n_acc + 4, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    accs = [f[:n_acc].view(H, W, 3) for f in flats]
+    cnts = [f[n_acc:] for f in flats]
+    cnt_host = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in flats]
     out = torch.empty_like(accs[0])
     overlap = world > 1 and not args.no_reduce_overlap
-    pending = None                                   # the previous step's reduce in flight: (works, acc, counts, staging)
+    pending = None                                   # the previous step's reduce in flight: (work, flat buffer, staging)
     step_no = 0
     totals = [0, 0]                                  # frames folded / dropped in the last finished stack (rank 0)
 
@@ -143,26 +148,22 @@ def main() -> None:
                           "warp_frames", "warp_launches", "fast_ms", "fast_launches", "fast_pixels")}
     last_stats = None
 
-    def start_reduce(acc, counts):
-        """The path's one exchange: sum of the per-rank accumulators (+ two counters) to rank 0. RCCL over xGMI."""
+    def start_reduce(flat):
+        """The path's one exchange: sum of the per-rank accumulators (+ the two counters behind them) to rank 0. RCCL over xGMI."""
         if args.rehearse_on_one_gpu:                 # gloo on CPU copies: control-flow rehearsal only
-            stage = (acc.cpu(), counts.cpu())
-            works = [dist.reduce(stage[0], dst=0, op=dist.ReduceOp.SUM, async_op=True),
-                     dist.reduce(stage[1], dst=0, op=dist.ReduceOp.SUM, async_op=True)]
-            return (works, acc, counts, stage)
-        works = [dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM, async_op=True),
-                 dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM, async_op=True)]
-        return (works, acc, counts, None)
+            stage = flat.cpu()
+            return (dist.reduce(stage, dst=0, op=dist.ReduceOp.SUM, async_op=True), flat, stage)
+        return (dist.reduce(flat, dst=0, op=dist.ReduceOp.SUM, async_op=True), flat, None)
 
     def finish_reduce(p):
-        works, acc, counts, stage = p
-        for w in works:
-            w.wait()                                 # RCCL: the current stream waits for the collective
+        work, flat, stage = p
+        work.wait()                                  # RCCL: the current stream waits for the collective
         if stage is not None:
-            acc.copy_(stage[0]); counts.copy_(stage[1])
+            flat.copy_(stage)
         if rank == 0:
-            totals[0], totals[1] = int(counts[0].item()), int(counts[1].item())
-            st.finalize_mean(acc, totals[0], out)
+            c = flat[n_acc:n_acc + 2].tolist()       # counters are small integers: exact in f32
+            totals[0], totals[1] = int(round(c[0])), int(round(c[1]))
+            st.finalize_mean(flat[:n_acc].view(H, W, 3), totals[0], out)
 
     def run_shard(src, acc, want_stats=False):
         # per-frame statistics are marshalled into Python objects only when asked for (the last step): that is host time of
@@ -177,7 +178,8 @@ def main() -> None:
 
     def step(record: bool, last: bool = False):
         nonlocal last_stats, pending, step_no
-        acc, counts = accs[step_no % len(accs)], cnts[step_no % len(accs)]
+        b = step_no % len(accs)
+        acc, counts, flat = accs[b], cnts[b], flats[b]
         step_no += 1
         added, dropped, stats = run_shard(frames, acc, want_stats=last)
         if record:
@@ -190,12 +192,12 @@ def main() -> None:
             totals[0], totals[1] = added, dropped
             st.finalize_mean(acc, added, out)
             return
-        counts[0] = added
-        counts[1] = dropped
+        cnt_host[b][0] = float(added); cnt_host[b][1] = float(dropped)
+        counts.copy_(cnt_host[b], non_blocking=True)
         if pending is not None:                      # its reduce ran under the alignment that just finished
             finish_reduce(pending)
             pending = None
-        p = start_reduce(acc, counts)
+        p = start_reduce(flat)
         if overlap:
             pending = p
         else:
