@@ -1,12 +1,14 @@
 // imread.cpp — the file front-end of the reference's entry points: `imgcodecs::imread(path,
-// IMREAD_UNCHANGED)` (utils.rs:110-117, 132) for the one family of formats this build can decode without external codec
-// libraries — binary PNM (P5 grey, P6 colour; 8 or 16 bit) — and keypoint_match / ecc_match in the reference's own call
-// shape, a list of paths (lib.rs:129-137, 702-710). 8-bit RGB / grey PNG is decoded through libpng's simplified API when
-// libpng16.so.16 can be loaded at run time (it is installed in the image, its headers are not: the four entry points and
-// the png_image struct of png.h 1.6 are declared below). JPEG / TIFF / other PNG flavours (alpha, 16-bit, palette) return
-// STK_NOT_IMPLEMENTED and the caller decodes them itself (the frame-based entry points are the boundary). Stripped 8/16-bit
-// grey / RGB TIFF goes through libtiff's handle-based API (TIFFOpen / TIFFGetField / TIFFReadScanline), loaded the same way. A file that is missing or not an image behaves as in the reference: imread gives an
-// empty Mat and the following cvtColor raises -> STK_BACKEND_ERROR (OpenCvError).
+// IMREAD_UNCHANGED)` (utils.rs:110-117, 132) and keypoint_match / ecc_match in the reference's own call shape, a list of
+// paths (lib.rs:129-137, 702-710). Decoded here: binary PNM (P5 grey, P6 colour; 8 or 16 bit) without any library; PNG
+// (8- and 16-bit grey / RGB, palette -> BGR, 1/2/4-bit grey -> 8 bit: libpng's row API, samples as stored, never
+// gamma-converted), JPEG (grey / YCbCr: libjpeg-turbo at its default settings, OpenCV's decoder family) and stripped 8/16-bit
+// grey / RGB TIFF (libtiff's handle API) through libpng16.so.16 / libjpeg.so.8 / libtiff.so.5 loaded at run time — the image
+// has the libraries but not their headers, so the entry points used are declared below. What the build does not take
+// (PNG with alpha or tRNS: the reference would stack four channels; tiled or compressed-planar TIFF; CMYK JPEG) returns
+// STK_NOT_IMPLEMENTED and the caller decodes it itself (the frame-based entry points are the boundary). A file that is
+// missing or not an image behaves as in the reference: imread gives an empty Mat and the following cvtColor raises ->
+// STK_BACKEND_ERROR (OpenCvError).
 #include <dlfcn.h>
 #include <setjmp.h>
 
@@ -467,8 +469,8 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
         const int rc = png_load(path, p, file);
         if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }                      // already decoded
         if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
-        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only 8-bit RGB / grey PNG without alpha is decoded in this "
-                                              "build (libpng16.so.16 " + (png_api().ok ? "loaded" : "not found") + ")");
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': PNG with an alpha channel or tRNS chunk is not decoded in this "
+                                              "build, nor any PNG when libpng is missing (libpng16.so.16 " + (png_api().ok ? "loaded" : "not found") + ")");
     }
     if (has_ext(path, ".tif") || has_ext(path, ".tiff")) {
         const int rc = tiff_load(path, p, file);
