@@ -176,6 +176,9 @@ void        stk_host_free(void* p);
  *                        0 every tap is gathered from global memory; the results are bit-identical
  *   "ecc_ring_lookahead" debug: frame-0 rows the ring keeps ahead of the row being fetched (5; 1..4 make its run-time check
  *                        fire, the strips then fall back to the gather loop: stk_timing.ecc_ring_fallbacks); same bits
+ *   "ecc_groups"         0 (default): by frame size; 2: the slots form two groups with their own (iterate, solve) launch sequences on
+ *                        two streams, one group's solve and launch boundaries running under the other's iteration pass (pays for
+ *                        frames up to 1080p with >= 32 slots); 1: one sequence. Per-frame results do not depend on it
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter
  *   "kp_lanes"           4 (default; 1..8): device-resident keypoint stacks of >= 16 frames are cut into this many runs of frames (at
  *                        least 8 each) that go through the pipeline side by side, the later ones on hidden helper contexts of

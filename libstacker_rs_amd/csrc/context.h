@@ -44,6 +44,7 @@ struct stk_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t copy_stream = nullptr;    // host -> HBM copies of host-fed stacks (upload.cpp)
     hipStream_t prep_stream = nullptr;    // grey + blur of frames that arrive while the ECC queue is already running
+    hipStream_t ecc_stream2 = nullptr;    // second launch sequence of the ECC queue (option ecc_groups = 2)
     std::vector<hipEvent_t> upload_events;
     hipEvent_t gate_ev = nullptr, gate_ev2 = nullptr;
     const FrameGate* frame_gate = nullptr;   // set by the path-based entry points for the duration of one call
@@ -63,6 +64,7 @@ struct stk_ctx {
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
     int opt_ecc_ring = 1;         // column-walking ECC pass: frame-0 rows through the per-wave LDS ring (0: always gather from global memory)
+    int opt_ecc_groups = 0;       // ECC slots in this many groups with their own launch sequences on two streams (stacker.cpp: ecc_run); 0 = by frame size
     int opt_ecc_ring_lookahead = 5;   // debug: frame-0 rows the ring keeps ahead (5 = production; less makes the run-time check fire and the strip fall back)
     int opt_ecc_variant = 3;      // ECC iteration kernel: 3 = production (column-walking homography pass / pipelined affine family), 0 = direct cross-check
     stk_timing timing{};

@@ -381,3 +381,31 @@ def test_streaming_grey_blur_is_bit_identical_to_the_tiled_kernel(stacker, depth
             continue
         assert torch.equal(a, b)
         assert all(np.array_equal(x["warp"], y["warp"]) and x["rho"] == y["rho"] for x, y in zip(sa, sb))
+
+
+def test_slot_groups_do_not_change_results(stacker):
+    """ecc_groups = 2 cuts the slots in two halves that run their (iterate, solve) launch sequences on two streams, sharing the
+    device-side queue (one half's solve runs under the other's iteration pass). Which slot, group or launch a frame lands
+    in must not show: iterations, warps and the stacked image bit for bit — device-resident, host-fed, and with fewer slots
+    than frames (the queue refills both groups)."""
+    frames, _ = synth.make_stack(70, 640, 480)
+    dev = frames.cuda()
+    pinned = frames.pin_memory()
+    res = {}
+    try:
+        for groups in (1, 2, 2):
+            stacker.set_option("ecc_groups", groups)
+            for name, src, slots in (("dev", dev, 0), ("host", pinned, 0), ("dev-12-slots", dev, 12)):
+                stacker.set_option("ecc_slots", slots)
+                out, st = stacker.ecc_match(src, PARAMS, return_stats=True)
+                cur = (out.cpu().numpy() if hasattr(out, "cpu") else out, [s["iterations"] for s in st], np.stack([s["warp"] for s in st]))
+                if name in res:
+                    assert cur[1] == res[name][1] and np.array_equal(cur[2], res[name][2]) and np.array_equal(cur[0], res[name][0]), (groups, name)
+                else:
+                    res[name] = cur
+    finally:
+        stacker.set_option("ecc_groups", 0)
+        stacker.set_option("ecc_slots", 0)
+    assert np.array_equal(res["dev"][0], res["host"][0]) and np.array_equal(res["dev"][0], res["dev-12-slots"][0])
+    with pytest.raises(Exception):
+        stacker.set_option("ecc_groups", 3)
