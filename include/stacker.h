@@ -143,8 +143,8 @@ stk_status  stk_create(int32_t device_id, stk_ctx** out);
  * run one host thread per device, sum the f32 accumulators and the {added, dropped} counters on device_ids[0] with
  * RCCL ncclReduce over xGMI (replaces try_reduce, lib.rs:321-335, 819-833) and scale there (lib.rs:339-345, 836-839).
  * Frames may be host memory or device memory on any of the devices (frames on another device are copied over once).
- * Per-frame results are bit-identical to the single-device run as long as every range holds at least "ecc_slots"
- * frames; the image differs by the order of the f32 adds only. n_devices == 1 returns a plain context. Stage-level and
+ * Per-frame results are bit-identical to the single-device run (a frame's summation partition depends on the frame size
+ * only); the image differs by the order of the f32 adds only. n_devices == 1 returns a plain context. Stage-level and
  * *_shard entry points on such a context run on device_ids[0]. RCCL (librccl.so.1) is loaded at this call. */
 stk_status  stk_create_multi(int32_t n_devices, const int32_t* device_ids, stk_ctx** out);
 /* The cut itself: rank `rank` of `world_size` aligns frames [first, first + count) of an n_frames stack (frame 0 is the
@@ -166,8 +166,9 @@ stk_status  stk_get_timing(const stk_ctx* ctx, stk_timing* out);
 stk_status  stk_host_alloc(size_t bytes, void** out);
 void        stk_host_free(void* p);
 /* Tuning knobs. None changes a frame's warp or the stacked image except where noted:
- *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto: up to 48, 64 for frames up to 1080p, the stack divided
- *                        evenly over the rounds); changes no result
+ *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto: the whole stack in one round up to 128 frames,
+ *                        beyond that at least three equal rounds of at most 96; rounds of at most 64 for frames up to 1080p;
+ *                        1..256); changes no result
  *   "ecc_blocks"         workgroups per ECC launch, all frames in flight together (0 = auto: 288 per frame); a non-zero
  *                        value changes the f32 summation partition, i.e. results at round-off level (within the stated
  *                        ECC tolerance)

@@ -136,7 +136,7 @@ stk_status stk_set_option(stk_ctx* ctx, const char* name, int64_t value) {
 
 stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     const std::string n(name);
-    if (n == "ecc_slots") { if (value < 0 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_slots out of range"); ctx->opt_ecc_slots = (int)value; }
+    if (n == "ecc_slots") { if (value < 0 || value > 256) return fail(ctx, STK_INVALID_PARAMS, "ecc_slots out of range"); ctx->opt_ecc_slots = (int)value; }
     else if (n == "warp_subpixel_bits") { if (value != 0 && value != 5) return fail(ctx, STK_INVALID_PARAMS, "warp_subpixel_bits must be 0 or 5"); ctx->opt_subpixel_bits = (int)value; }
     else if (n == "profile") ctx->opt_profile = (int)value;
     else if (n == "ecc_chunk") { if (value < 1 || value > 64) return fail(ctx, STK_INVALID_PARAMS, "ecc_chunk out of range"); ctx->opt_ecc_chunk = (int)value; }
@@ -198,19 +198,29 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     const int P = motion == STK_MOTION_HOMOGRAPHY ? 8 : motion == STK_MOTION_AFFINE ? 6 : motion == STK_MOTION_EUCLIDEAN ? 3 : 2;
     pl.nsums = ecc_nsums(P);
     // Frames in flight per launch ("slots"). Every (iterate, solve) launch pair costs ~25 us of solve latency and launch
-    // gaps whatever it carries, so the more frames share it the better — up to a point: past ~48 4K frames the launches get
-    // less efficient per frame than the saved pairs are worth. And the stack should go through the slots in equal rounds:
-    // 63 frames in 48 slots leave a second round of 15. So: at most 48 slots (64 up to 1080p), and the frames divided evenly
-    // over the rounds that takes. Measured: 255 x 4K frames 32 slots 59.0 ms, 43 slots 57.6, 48 58.5, 64 58.3; 63 x 1080p
-    // 32 slots 3.91 ms, 48 4.30, 63 3.76.
+    // gaps whatever it carries, so the more frames share it the better; and the stack should go through the slots in EQUAL
+    // rounds (63 frames in 48 slots leave a second round of 15). Round 3, re-measured with the column-walking kernel (A/B
+    // within one call, ms per stack): what costs most is a SECOND round — its frames enter as the first round's converge,
+    // all within a few launches of each other, and every launch from there to the end is part empty. 4K: 63 frames in one
+    // round of 63 slots 14.4-14.6, in two rounds of 32 15.7-16.0; 95 frames 95 slots 21.4-21.8, 2 x 48 22.2-22.4; 127 frames
+    // 127 slots 28.1, 3 x 43 28.4; 255 frames 3 x 85 55.9-56.1, 73 / 102 slots 55.9 / 56.2, 5 x 51 56.1-56.5, 6 x 43 56.6-57.0,
+    // 1 x 255 56.1-56.4 (nothing hides the templates' preparation), 2 x 128 57.4-57.6, 4 x 64 56.9-57.3. So: one round up to
+    // 128 frames; beyond, at least three equal rounds of at most 96 (4K class) — 64 slots per round for frames up to 1080p
+    // as before (63 x 1080p: 32 slots 3.91 ms, 48 4.30, 63 3.76).
     // Workgroups per frame: a function of the FRAME SIZE only (288 at 4K, see below), so a frame's f32 summation partition
     // depends on nothing else: its warp is bit-identical however the stack is sharded over GPUs and however many frames
     // happen to share the launch.
     int slots = ctx->opt_ecc_slots;
     if (slots <= 0) {
-        const int cap = (size_t)w * h <= (size_t)1920 * 1088 ? 64 : 48;
-        const int rounds = (std::max(n_templates, 1) + cap - 1) / cap;
-        slots = (std::max(n_templates, 1) + rounds - 1) / rounds;
+        const int nt = std::max(n_templates, 1);
+        if ((size_t)w * h <= (size_t)1920 * 1088) {
+            const int rounds = (nt + 63) / 64;
+            slots = (nt + rounds - 1) / rounds;
+        } else if (nt <= 128) slots = nt;
+        else {
+            const int rounds = std::max(3, (nt + 95) / 96);
+            slots = (nt + rounds - 1) / rounds;
+        }
     }
     pl.n_slots = std::max(1, std::min(slots, std::max(n_templates, 1)));
     // Round 3: a wavefront walks ~112 rows of a 64-pixel column strip before it folds its 66 sums across the lanes (266

@@ -6,7 +6,7 @@ the guide says to double it for 16-B-per-lane streams and to calibrate other acc
 calibration rows are in the same run: `scale_kernel` (float4 stream, 4 B read per float), `grey_blur_u8c3_kernel`
 (aligned dword loads of a BGR byte stream: 3 B/px read, 4 B/px written) and `warp_accumulate_u8c3_kernel` (unaligned
 8-byte gathers: ~3 B/px/frame). `_calibration` lists raw FETCH_SIZE / known bytes for each.
-`_kernel_source_sha256` pins the summary to the ECC sources it was measured with — kernels_ecc_col.hip, kernels_ecc_solve.hip,
+`_kernel_source_sha256` pins the summary to the ECC sources it was measured with (kernels AND the host schedule: slots per launch, workgroups per frame) — kernels_ecc_col.hip, kernels_ecc_solve.hip, kernels_ecc.hip, stacker.cpp,
 ecc_solve_body.h, concatenated — (bench.py ignores a stale one)."""
 import collections
 import csv
@@ -55,8 +55,8 @@ for k, v in res.items():
 out = dict(res)
 # pins the summary to the ECC sources it was measured with: iteration pass, solve / init kernels, solve routine
 h = hashlib.sha256()
-for name in ('kernels_ecc_col.hip', 'kernels_ecc_solve.hip', 'ecc_solve_body.h'):
+for name in ('kernels_ecc_col.hip', 'kernels_ecc_solve.hip', 'ecc_solve_body.h', 'kernels_ecc.hip', 'stacker.cpp'):
     h.update(open(os.path.join(root, 'libstacker_rs_amd', 'csrc', name), 'rb').read())
 out['_kernel_source_sha256'] = h.hexdigest()
-out['_kernel_source_files'] = ['kernels_ecc_col.hip', 'kernels_ecc_solve.hip', 'ecc_solve_body.h']
+out['_kernel_source_files'] = ['kernels_ecc_col.hip', 'kernels_ecc_solve.hip', 'ecc_solve_body.h', 'kernels_ecc.hip', 'stacker.cpp']
 print(json.dumps(out, indent=1, sort_keys=True))
