@@ -56,7 +56,7 @@ struct stk_ctx {
     int opt_ecc_slots = 0;        // 0 = auto
     int opt_subpixel_bits = 0;
     int opt_profile = 1;
-    int opt_ecc_chunk = 4;
+    int opt_ecc_chunk = 0;        // (iterate, solve) pairs between two polls of the completion counter; 0 = by frame size (stacker.cpp: ecc_run)
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
     bool opt_orb_resize_tables = true; // ORB pyramid steps by the table-driven kernel (false: tables computed per tile, round 2's kernel; same bits)
     bool opt_orb_patch_blur = true;  // ORB: the descriptor kernel blurs the window it reads (false: blur every level whole, then sample)
