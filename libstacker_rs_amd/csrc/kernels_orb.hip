@@ -752,11 +752,72 @@ __global__ __launch_bounds__(256) void fast_describe_all_kernel(const uint8_t* _
                        sel + blockIdx.z * bs.sel + (size_t)l * sel_cap, sel_cap, um);
 }
 
+// The Harris cull on the device (round 3; it was ~150 us of host work per lane, on the critical path of a stack's last lane).
+// One workgroup per (level, frame): the short list (<= ORB_CULL_MAX entries, 2 n_l + ties) is sorted by the key
+// (harris descending, y, x) — one 64-bit integer: the float's order-preserving image, complemented, above y << 16 | x —
+// with a bitonic network in LDS; KeyPointsFilter::retainBest keeps the n_l best and everything that ties with the n_l-th,
+// which in sorted order is a prefix; the prefix goes out in that order, which is the order the host gave them. Harris
+// responses are finite and never -0 (a difference of products times a positive scale), so the integer order IS the
+// comparator's order. A level with more than ORB_CULL_MAX short-listed or ORB_KEEP_PACK kept corners is flagged (-1) and
+// culled by the host as before.
+__device__ __forceinline__ unsigned long long cull_key(float harris, int xy) {
+    unsigned hb = __float_as_uint(harris);
+    if ((hb << 1) == 0) hb = 0;                                   // (-0 cannot occur; keep the order total anyway)
+    const unsigned asc = (hb & 0x80000000u) ? ~hb : (hb | 0x80000000u);
+    return ((unsigned long long)(~asc) << 32) | (unsigned)(((xy >> 16) << 16) | (xy & 0xffff));
+}
+
+__global__ __launch_bounds__(256) void orb_cull_all_kernel(const OrbLevelState* __restrict__ st, const OrbSelected* __restrict__ sel, int sel_cap,
+                                                           OrbLevelTable L, OrbKept* __restrict__ kept, int* __restrict__ kept_cnt, OrbBatch bs) {
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    st += f * bs.states + l;
+    sel += f * bs.sel + (size_t)l * sel_cap;
+    kept += ((size_t)f * ORB_LEVELS + l) * ORB_KEEP_PACK;
+    const int n = st->n_sel, keep = L.keep[l] / 2;                // keep[] is the short list's 2 n_l
+    if (n > ORB_CULL_MAX || n > sel_cap) { if (tid == 0) kept_cnt[f * ORB_LEVELS + l] = -1; return; }
+    __shared__ unsigned long long key[ORB_CULL_MAX];
+    __shared__ unsigned short idx[ORB_CULL_MAX];
+    __shared__ int cnt_s;
+    for (int i = tid; i < ORB_CULL_MAX; i += 256) {
+        key[i] = i < n ? cull_key(sel[i].harris, sel[i].xy) : ~0ull;
+        idx[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= ORB_CULL_MAX; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < ORB_CULL_MAX; i += 256) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = key[i], b = key[p];
+                    if ((a > b) == up) { key[i] = b; key[p] = a; const unsigned short t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    // the kept prefix: everything when the list is not longer than n_l, else n_l + the ties with the n_l-th response
+    if (tid == 0) cnt_s = keep <= 0 ? 0 : min(n, keep);
+    __syncthreads();
+    if (keep > 0 && n > keep) {
+        const unsigned thr_hi = (unsigned)(key[keep - 1] >> 32);
+        for (int i = keep + tid; i < n; i += 256)
+            if ((unsigned)(key[i] >> 32) == thr_hi) atomicAdd(&cnt_s, 1);          // ties are contiguous behind the n_l-th
+    }
+    __syncthreads();
+    const int cnt = cnt_s;
+    if (cnt > ORB_KEEP_PACK) { if (tid == 0) kept_cnt[f * ORB_LEVELS + l] = -1; return; }
+    for (int i = tid; i < cnt; i += 256) {
+        const OrbSelected e = sel[idx[i]];
+        kept[i] = OrbKept{e.xy, e.harris, e.m01, e.m10};
+    }
+    if (tid == 0) kept_cnt[f * ORB_LEVELS + l] = cnt;
+}
+
 // FAST + short list of ALL levels of a batch in four launches (instead of four per level). Returns hipErrorNotSupported when
 // a level does not qualify for the tiled kernel (tiny or unaligned levels): the caller then goes level by level.
 hipError_t launch_fast_all(const uint8_t* pyr, const OrbLevelTable& L, int thr, int edge, OrbLevelState* st, OrbCandidate* cand,
                            OrbSelected* sel, int sel_cap, const OrbUmax& um, hipStream_t s, int n_frames, size_t pyr_stride,
-                           size_t states_stride, size_t cand_stride, size_t sel_stride) {
+                           size_t states_stride, size_t cand_stride, size_t sel_stride, OrbKept* kept, int* kept_cnt) {
     const OrbBatch bs{pyr_stride, states_stride, cand_stride, sel_stride};
     if ((reinterpret_cast<uintptr_t>(pyr) & 3) != 0 || (pyr_stride & 3) != 0) return hipErrorNotSupported;
     for (int l = 0; l < ORB_LEVELS; l++)
@@ -766,6 +827,7 @@ hipError_t launch_fast_all(const uint8_t* pyr, const OrbLevelTable& L, int thr, 
     fast_threshold_all_kernel<<<dim3(ORB_LEVELS, n_frames), 64, 0, s>>>(st, L, bs);
     fast_pick_all_kernel<<<dim3(64, ORB_LEVELS, n_frames), 64, 0, s>>>(st, cand, L, sel, sel_cap, bs);
     fast_describe_all_kernel<<<dim3(32, ORB_LEVELS, n_frames), 256, 0, s>>>(pyr, L, st, sel, sel_cap, um, bs);
+    if (kept && kept_cnt) orb_cull_all_kernel<<<dim3(ORB_LEVELS, n_frames), 256, 0, s>>>(st, sel, sel_cap, L, kept, kept_cnt, bs);
     return hipGetLastError();
 }
 

@@ -39,12 +39,14 @@ using namespace stk;
 namespace stk {
 
 struct KeypointWorkspace {
-    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn, gfull, counts, rtab;
+    DevBuf pyr, score, blur, tmpf, cand, sel, states, final_kps, desc0, desc, knn, gfull, counts, rtab, kept, kept_cnt;
     bool pattern_uploaded = false;
     int rtab_w = 0, rtab_h = 0;             // level-0 size the resize tables in `rtab` were computed for
     size_t rtab_ofs[ORB_LEVELS] = {};       // ints into rtab: tables of the step level l - 1 -> l
     OrbSelected* host_sel = nullptr;        // pinned: [frames][ORB_LEVELS][ORB_PACK] head of every short list
     OrbLevelState* host_states = nullptr;   // pinned: [frames][ORB_LEVELS]
+    OrbKept* host_kept = nullptr;           // pinned: [frames][ORB_LEVELS][ORB_KEEP_PACK] what the device-side cull kept, in order
+    int* host_kept_cnt = nullptr;           // pinned: [frames][ORB_LEVELS] (-1: that level's short list is culled here)
     OrbFinalKeypoint* host_final = nullptr; // pinned: the kept keypoints of a batch, back to back (read by an async copy)
     size_t host_final_cap = 0;
     int* host_knn = nullptr;                // pinned
@@ -54,10 +56,12 @@ struct KeypointWorkspace {
 KeypointWorkspace* keypoint_workspace_create() { return new KeypointWorkspace(); }
 void keypoint_workspace_destroy(KeypointWorkspace* k) {
     if (!k) return;
-    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn, &k->gfull, &k->counts, &k->rtab})
+    for (DevBuf* b : {&k->pyr, &k->score, &k->blur, &k->tmpf, &k->cand, &k->sel, &k->states, &k->final_kps, &k->desc0, &k->desc, &k->knn, &k->gfull, &k->counts, &k->rtab, &k->kept, &k->kept_cnt})
         b->release();
     if (k->host_sel) (void)hipHostFree(k->host_sel);
     if (k->host_states) (void)hipHostFree(k->host_states);
+    if (k->host_kept) (void)hipHostFree(k->host_kept);
+    if (k->host_kept_cnt) (void)hipHostFree(k->host_kept_cnt);
     if (k->host_knn) (void)hipHostFree(k->host_knn);
     if (k->host_final) (void)hipHostFree(k->host_final);
     delete k;
@@ -196,7 +200,8 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     hipError_t fe = hipErrorNotSupported;
     if (all_ok) {
         fe = launch_fast_all(pyr, L, ORB_FAST_THRESHOLD, ORB_EDGE, st, ws->cand.as<OrbCandidate>(), ws->sel.as<OrbSelected>(), ORB_SEL_CAP,
-                             g.umax, s, n_frames, PT, ORB_LEVELS, g.cand_total, SELF);
+                             g.umax, s, n_frames, PT, ORB_LEVELS, g.cand_total, SELF,
+                             ctx->opt_orb_device_cull ? ws->kept.as<OrbKept>() : nullptr, ctx->opt_orb_device_cull ? ws->kept_cnt.as<int>() : nullptr);
         if (fe != hipSuccess && fe != hipErrorNotSupported) return fail(ctx, STK_HIP_ERROR, std::string("FAST: ") + hipGetErrorString(fe));
     }
     for (int l = 0; l < ORB_LEVELS; l++) {
@@ -218,9 +223,16 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     HIP_TRY(hipEventRecord(ctx->gate_ev2, s));
     HIP_TRY(hipStreamWaitEvent(ds, ctx->gate_ev2, 0));
     HIP_TRY(hipMemcpyAsync(ws->host_states, st, sizeof(OrbLevelState) * ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, ds));
-    // the head of every short list in one strided copy (rows = (frame, level), ORB_PACK of ORB_SEL_CAP entries each)
-    HIP_TRY(hipMemcpy2DAsync(ws->host_sel, sizeof(OrbSelected) * ORB_PACK, ws->sel.p, sizeof(OrbSelected) * ORB_SEL_CAP,
-                             sizeof(OrbSelected) * ORB_PACK, (size_t)ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, ds));
+    // device-side cull (the all-levels launch took it along): what was kept, in order, and a count per (frame, level) — a third of
+    // the bytes of the short lists; else the head of every short list in one strided copy (rows = (frame, level), ORB_PACK
+    // of ORB_SEL_CAP entries each)
+    const bool device_cull = fe == hipSuccess && ctx->opt_orb_device_cull;
+    if (device_cull) {
+        HIP_TRY(hipMemcpyAsync(ws->host_kept_cnt, ws->kept_cnt.p, sizeof(int) * ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, ds));
+        HIP_TRY(hipMemcpyAsync(ws->host_kept, ws->kept.p, sizeof(OrbKept) * ORB_KEEP_PACK * ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, ds));
+    } else
+        HIP_TRY(hipMemcpy2DAsync(ws->host_sel, sizeof(OrbSelected) * ORB_PACK, ws->sel.p, sizeof(OrbSelected) * ORB_SEL_CAP,
+                                 sizeof(OrbSelected) * ORB_PACK, (size_t)ORB_LEVELS * n_frames, hipMemcpyDeviceToHost, ds));
     HIP_TRY(hipEventRecord(ctx->gate_ev, ds));
     // The 7x7 blur of every level (the descriptor stage's input) does not depend on the host's Harris cull: it is queued
     // now and runs while the host works on the short lists (the host waits for the copies above only, not for the stream).
@@ -243,7 +255,7 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
         for (int l = 0; l < ORB_LEVELS; l++) {
             const int n = ws->host_states[f * ORB_LEVELS + l].n_sel;
             if (n > ORB_SEL_CAP) return fail(ctx, STK_PROCESSING_ERROR, "ORB: more tied FAST corners than the short list holds");
-            if (n > ORB_PACK) {
+            if (device_cull ? ws->host_kept_cnt[f * ORB_LEVELS + l] < 0 : n > ORB_PACK) {
                 auto& v = big[(size_t)f * ORB_LEVELS + l];
                 v.resize(n);
                 HIP_TRY(hipMemcpy(v.data(), ws->sel.as<OrbSelected>() + (size_t)f * SELF + (size_t)l * ORB_SEL_CAP,
@@ -264,26 +276,33 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
         for (int l = 0; l < ORB_LEVELS; l++) {
             const int n = ws->host_states[f * ORB_LEVELS + l].n_sel;
             const auto& bv = big[(size_t)f * ORB_LEVELS + l];
-            const OrbSelected* src = n > ORB_PACK ? bv.data() : ws->host_sel + ((size_t)f * ORB_LEVELS + l) * ORB_PACK;
-            // cull to n_l by the Harris response (KeyPointsFilter::retainBest: everything >= the n_l-th best stays, ties
-            // included), then a deterministic order
-            const int keep = g.nfeatures[l];
-            float thr = -FLT_MAX;
-            if (keep == 0) thr = FLT_MAX;
-            else if (keep > 0 && n > keep) {
-                resp.resize(n);
-                for (int i = 0; i < n; i++) resp[i] = src[i].harris;
-                std::nth_element(resp.begin(), resp.begin() + (keep - 1), resp.end(), std::greater<float>());
-                thr = resp[keep - 1];
+            const int kc = device_cull ? ws->host_kept_cnt[f * ORB_LEVELS + l] : -1;
+            if (kc >= 0) {                                     // culled and ordered on the device
+                const OrbKept* kp = ws->host_kept + ((size_t)f * ORB_LEVELS + l) * ORB_KEEP_PACK;
+                v.resize(kc);
+                for (int i = 0; i < kc; i++) { v[i].xy = kp[i].xy; v[i].score = 0; v[i].harris = kp[i].harris; v[i].m01 = kp[i].m01; v[i].m10 = kp[i].m10; v[i].pad = 0; }
+            } else {
+                const OrbSelected* src = !bv.empty() ? bv.data() : ws->host_sel + ((size_t)f * ORB_LEVELS + l) * ORB_PACK;
+                // cull to n_l by the Harris response (KeyPointsFilter::retainBest: everything >= the n_l-th best stays, ties
+                // included), then a deterministic order
+                const int keep = g.nfeatures[l];
+                float thr = -FLT_MAX;
+                if (keep == 0) thr = FLT_MAX;
+                else if (keep > 0 && n > keep) {
+                    resp.resize(n);
+                    for (int i = 0; i < n; i++) resp[i] = src[i].harris;
+                    std::nth_element(resp.begin(), resp.begin() + (keep - 1), resp.end(), std::greater<float>());
+                    thr = resp[keep - 1];
+                }
+                v.clear();
+                for (int i = 0; i < n; i++) if (keep != 0 && src[i].harris >= thr) v.push_back(src[i]);
+                std::sort(v.begin(), v.end(), [](const OrbSelected& p, const OrbSelected& q) {
+                    if (p.harris != q.harris) return p.harris > q.harris;
+                    const int py = p.xy >> 16, qy = q.xy >> 16;
+                    if (py != qy) return py < qy;
+                    return (p.xy & 0xffff) < (q.xy & 0xffff);
+                });
             }
-            v.clear();
-            for (int i = 0; i < n; i++) if (keep != 0 && src[i].harris >= thr) v.push_back(src[i]);
-            std::sort(v.begin(), v.end(), [](const OrbSelected& p, const OrbSelected& q) {
-                if (p.harris != q.harris) return p.harris > q.harris;
-                const int py = p.xy >> 16, qy = q.xy >> 16;
-                if (py != qy) return py < qy;
-                return (p.xy & 0xffff) < (q.xy & 0xffff);
-            });
             const float sc = g.scale[l], inv = 1.f / sc, size = 31 * sc;
             for (const OrbSelected& k : v) {
                 HostKeypoint hk;
@@ -336,10 +355,16 @@ stk_status orb_prepare(stk_ctx* ctx, KeypointWorkspace* ws, int w, int h, OrbGeo
     HIP_TRY(ws->cand.reserve(g.cand_total * sizeof(OrbCandidate) * F));
     HIP_TRY(ws->sel.reserve(sizeof(OrbSelected) * ORB_SEL_CAP * ORB_LEVELS * F));
     HIP_TRY(ws->states.reserve(sizeof(OrbLevelState) * ORB_LEVELS * F));
+    HIP_TRY(ws->kept.reserve(sizeof(OrbKept) * ORB_KEEP_PACK * ORB_LEVELS * F));
+    HIP_TRY(ws->kept_cnt.reserve(sizeof(int) * ORB_LEVELS * F));
     if (ws->host_frames_cap < F) {
         if (ws->host_sel) (void)hipHostFree(ws->host_sel);
         if (ws->host_states) (void)hipHostFree(ws->host_states);
-        ws->host_sel = nullptr; ws->host_states = nullptr; ws->host_frames_cap = 0;
+        if (ws->host_kept) (void)hipHostFree(ws->host_kept);
+        if (ws->host_kept_cnt) (void)hipHostFree(ws->host_kept_cnt);
+        ws->host_sel = nullptr; ws->host_states = nullptr; ws->host_kept = nullptr; ws->host_kept_cnt = nullptr; ws->host_frames_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&ws->host_kept, sizeof(OrbKept) * ORB_KEEP_PACK * ORB_LEVELS * F, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&ws->host_kept_cnt, sizeof(int) * ORB_LEVELS * F, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&ws->host_sel, sizeof(OrbSelected) * ORB_PACK * ORB_LEVELS * F, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&ws->host_states, sizeof(OrbLevelState) * ORB_LEVELS * F, hipHostMallocDefault));
         ws->host_frames_cap = F;
@@ -726,7 +751,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 if ((st = stk_create(ctx->device, &hk))) return fail(ctx, st, "keypoint lane: helper context creation failed");
                 (void)hipSetDevice(ctx->device);
             }
-            hk->opt_kp_workers = ctx->opt_kp_workers; hk->opt_orb_patch_blur = ctx->opt_orb_patch_blur; hk->opt_orb_resize_tables = ctx->opt_orb_resize_tables; hk->opt_profile = ctx->opt_profile;
+            hk->opt_kp_workers = ctx->opt_kp_workers; hk->opt_orb_patch_blur = ctx->opt_orb_patch_blur; hk->opt_orb_resize_tables = ctx->opt_orb_resize_tables; hk->opt_orb_device_cull = ctx->opt_orb_device_cull; hk->opt_profile = ctx->opt_profile;
             hk->opt_upload_batch = ctx->opt_upload_batch;
             timing_begin(hk);
             if (threads > 1) hk->shared_pool = ctx->shared_pool ? ctx->shared_pool : ctx->host_pool;

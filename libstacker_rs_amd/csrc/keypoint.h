@@ -24,6 +24,11 @@ struct OrbLevelTable {
     int cand_cap[ORB_LEVELS], keep[ORB_LEVELS];
 };
 struct OrbFinalKeypoint { int level, cx, cy; float cos_a, sin_a; int frame, row; };   // row: descriptor row to write
+// a level's kept corners after the Harris cull (KeyPointsFilter::retainBest: the n_l best and everything that ties with the
+// n_l-th), in the order (harris descending, y, x): orb_cull_all_kernel
+struct OrbKept { int xy; float harris; int m01, m10; };
+constexpr int ORB_KEEP_PACK = 256;       // kept corners per level the device-side cull hands over (n_l <= ~110 + ties; else the host culls that level)
+constexpr int ORB_CULL_MAX = 512;        // short-list length the device-side cull sorts (2 n_l + ties; else the host culls that level)
 
 struct KeypointWorkspace;
 class HostPool;
@@ -49,9 +54,10 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
                              OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,
                              const OrbUmax& um, hipStream_t s, int n_frames = 1, size_t pyr_stride = 0,
                              size_t states_stride = 0, size_t cand_stride = 0, size_t sel_stride = 0);
+// kept / kept_cnt (null: no device-side cull): per (frame, level) ORB_KEEP_PACK entries and a count (-1: that level is left to the host)
 hipError_t launch_fast_all(const uint8_t* pyr, const OrbLevelTable& L, int thr, int edge, OrbLevelState* st, OrbCandidate* cand,
                            OrbSelected* sel, int sel_cap, const OrbUmax& um, hipStream_t s, int n_frames, size_t pyr_stride,
-                           size_t states_stride, size_t cand_stride, size_t sel_stride);
+                           size_t states_stride, size_t cand_stride, size_t sel_stride, OrbKept* kept = nullptr, int* kept_cnt = nullptr);
 hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, float* tmp, uint8_t* dst, hipStream_t s,
                          int n_frames = 1, size_t pyr_stride = 0, size_t tmp_stride = 0);
 hipError_t upload_orb_pattern(const signed char* p);

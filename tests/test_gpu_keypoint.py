@@ -348,3 +348,39 @@ def test_orb_table_driven_pyramid_equals_the_per_tile_tables(stacker):
     assert n_total > 500
     ko, do = oracle.orb_detect_and_compute(imgs[1])
     assert np.array_equal(got[1][1][0], ko) and np.array_equal(got[1][1][1], do)
+
+
+def test_orb_device_cull_equals_the_host_cull(stacker):
+    """The Harris cull (KeyPointsFilter::retainBest: the n_l best per level and everything that ties with the n_l-th) and the
+    ordering (response descending, y, x) run on the device by default (one bitonic sort per level and frame on an integer
+    key); the host's nth_element + sort (orb_device_cull = 0) must give the same keypoints and descriptors — on textured
+    images, on a periodic pattern (hundreds of exactly tied responses: the tie rule, and short lists longer than the device
+    sorts, which fall back to the host per level), and through keypoint_match."""
+    from libstacker_rs_amd import KeyPointMatchParameters, RANSAC, synth
+    rng = np.random.default_rng(11)
+    imgs = []
+    for (h, w) in [(480, 640), (301, 517), (1080, 1920)]:
+        base = np.kron(rng.integers(0, 256, ((h + 5) // 6, (w + 5) // 6)), np.ones((6, 6)))[:h, :w]
+        imgs.append(np.clip(base * 0.8 + rng.integers(0, 50, (h, w)), 0, 255).astype(np.uint8))
+    yy, xx = np.mgrid[0:600, 0:800]
+    imgs.append((((xx // 8 + yy // 8) % 2) * 200 + 20).astype(np.uint8))          # checkerboard: every corner ties with hundreds of others
+    tile = rng.integers(0, 256, (16, 16)).astype(np.uint8)
+    imgs.append(np.tile(tile, (40, 50)))                                          # 640 x 800 of one repeated 16 x 16 tile
+    frames, _ = synth.make_stack(17, 640, 480, device="cuda")
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    got = {}
+    try:
+        for mode in (1, 0):
+            stacker.set_option("orb_device_cull", mode)
+            single = [stacker.orb_detect_and_compute(g, 4096) for g in imgs]
+            d, out, stats = stacker.keypoint_match(frames, kp, return_stats=True)
+            got[mode] = (single, d, out.cpu().numpy(), np.stack([s["warp"] for s in stats]))
+    finally:
+        stacker.set_option("orb_device_cull", 1)
+    for i, ((k1, d1), (k0, d0)) in enumerate(zip(got[1][0], got[0][0])):
+        assert k1.shape == k0.shape and np.array_equal(k1, k0) and np.array_equal(d1, d0), i
+    assert sum(len(k) for k, _ in got[1][0]) > 1500
+    assert got[1][1] == got[0][1] and np.array_equal(got[1][3], got[0][3]) and np.array_equal(got[1][2], got[0][2])
+    for i in (1, 3, 4):                                                           # and against the oracle
+        ko, do = oracle.orb_detect_and_compute(imgs[i])
+        assert np.array_equal(got[1][0][i][0], ko) and np.array_equal(got[1][0][i][1], do), i
