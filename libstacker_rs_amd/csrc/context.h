@@ -44,6 +44,7 @@ struct stk_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t copy_stream = nullptr;    // host -> HBM copies of host-fed stacks (upload.cpp)
     hipStream_t prep_stream = nullptr;    // grey + blur of frames that arrive while the ECC queue is already running
+    hipStream_t tail_stream = nullptr;    // highest priority: the keypoint lanes' descriptor / 2-NN / homography launches (keypoint.cpp)
     hipStream_t ecc_stream2 = nullptr;    // second launch sequence of the ECC queue (option ecc_groups = 2)
     std::vector<hipEvent_t> upload_events;
     hipEvent_t gate_ev = nullptr, gate_ev2 = nullptr;

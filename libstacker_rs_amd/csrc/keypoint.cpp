@@ -172,7 +172,7 @@ void parallel_for(stk_ctx* ctx, int n, int threads, F fn) {
 // (Harris cull, ordering, angles) run on `threads` host threads. Descriptors are left on the device in `desc_dev`,
 // frame f in rows [f * MAX_KP, f * MAX_KP + out[f].size()) — by work still QUEUED on `s` when this returns.
 stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const OrbGeometry& g, int n_frames, int threads,
-                   uint8_t* desc_dev, std::vector<std::vector<HostKeypoint>>& out) {
+                   uint8_t* desc_dev, std::vector<std::vector<HostKeypoint>>& out, hipStream_t tail = nullptr) {
     uint8_t* pyr = ws->pyr.as<uint8_t>();
     uint8_t* score = ws->score.as<uint8_t>();
     OrbLevelState* st = ws->states.as<OrbLevelState>();
@@ -341,9 +341,12 @@ stk_status orb_run(stk_ctx* ctx, KeypointWorkspace* ws, hipStream_t s, const Orb
     n_all = 0;
     for (auto& fin : fins) { std::memcpy(ws->host_final + n_all, fin.data(), sizeof(OrbFinalKeypoint) * fin.size()); n_all += fin.size(); }
     HIP_TRY(ws->final_kps.reserve(sizeof(OrbFinalKeypoint) * n_all));
-    HIP_TRY(hipMemcpyAsync(ws->final_kps.p, ws->host_final, sizeof(OrbFinalKeypoint) * n_all, hipMemcpyHostToDevice, s));
-    if (patch_blur) HIP_TRY(launch_brief_patch(pyr, g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)n_all, g.g7, desc_dev, s, PT));
-    else HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)n_all, desc_dev, s, PT));
+    // the descriptor stage goes to `tail` when the caller has one (a high-priority stream: everything it depends on has been
+    // waited for by the host above); the whole-level blur path stays on `s`, behind its blur launches
+    hipStream_t bs = patch_blur && tail ? tail : s;
+    HIP_TRY(hipMemcpyAsync(ws->final_kps.p, ws->host_final, sizeof(OrbFinalKeypoint) * n_all, hipMemcpyHostToDevice, bs));
+    if (patch_blur) HIP_TRY(launch_brief_patch(pyr, g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)n_all, g.g7, desc_dev, bs, PT));
+    else HIP_TRY(launch_brief(ws->blur.as<uint8_t>(), g.pyr, ws->final_kps.as<OrbFinalKeypoint>(), (int)n_all, desc_dev, bs, PT));
     return STK_OK;
 }
 
@@ -576,6 +579,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
         if ((st = orb_prepare(c, c->kp, ew, eh, g, batch))) return st;
         KeypointWorkspace* ws = c->kp;
         hipStream_t s = c->stream;
+        struct TailIdle { hipStream_t t; ~TailIdle() { if (t) (void)hipStreamSynchronize(t); } } tail_idle{c->tail_stream};   // nothing of this lane stays queued on its tail stream, whatever the exit
         if (scaled) HIP_TRY_C(c, ws->gfull.reserve((size_t)w * h));
         HIP_TRY_C(c, ws->desc0.reserve(MAX_KP * 32));
         HIP_TRY_C(c, ws->desc.reserve(MAX_KP * 32 * (size_t)batch));
@@ -615,14 +619,20 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                     if ((st = grey_level0(dev[b0 + k], k))) return st;
             std::vector<std::vector<HostKeypoint>> kps;
             KPT(c, "lane: batch start");
-            if ((st = orb_run(c, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps))) return st;   // descriptors: queued on s
+            // The lane's TAIL — descriptors, 2-NN, homography: microseconds of kernels between host steps — runs on a high-priority
+            // stream: on the engine's stream these launches queue behind the other lanes' FAST and fold launches, which fill
+            // the device (a 8 us model-scoring launch took 30-160 us to come back, a 58 us refinement 80-145): 2.41 -> 2.38 ms per
+            // 64 x 1080p stack, six A/B pairs in one call — the priority helps a launch onto the device, not through it. The blur-whole-
+            // level path keeps everything on s (the descriptors there depend on launches queued on s).
+            const hipStream_t ts = c->opt_orb_patch_blur && c->tail_stream ? c->tail_stream : s;
+            if ((st = orb_run(c, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps, ts))) return st;   // descriptors: queued on ts
             int first = 0;                                         // first moving frame of this batch
             if (b0 == 0) {
                 std::lock_guard<std::mutex> lk(ref.m);
                 ref.kp0 = kps[0];
                 ref.n0 = (int)ref.kp0.size();
-                if (ref.n0 > 0) HIP_TRY_C(c, hipMemcpyAsync(ws->desc0.p, ws->desc.p, (size_t)ref.n0 * 32, hipMemcpyDeviceToDevice, s));
-                HIP_TRY_C(c, hipEventRecord(ref.ev, s));
+                if (ref.n0 > 0) HIP_TRY_C(c, hipMemcpyAsync(ws->desc0.p, ws->desc.p, (size_t)ref.n0 * 32, hipMemcpyDeviceToDevice, ts));
+                HIP_TRY_C(c, hipEventRecord(ref.ev, ts));
                 ref.desc0 = ws->desc0.as<uint8_t>();
                 ref.ready = true;
                 ref.cv.notify_all();
@@ -633,20 +643,20 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 ref.cv.wait(lk, [&]() { return ref.ready || ref.failed; });
                 if (ref.failed) return STK_PROCESSING_ERROR;       // lane 0 reports its own error
                 kp0 = &ref.kp0; n0 = ref.n0; desc0 = ref.desc0;
-                if (lo != 0) HIP_TRY_C(c, hipStreamWaitEvent(s, ref.ev, 0));   // the other lane's copy into desc0
+                if (lo != 0) HIP_TRY_C(c, hipStreamWaitEvent(ts, ref.ev, 0));  // the other lane's copy into desc0
             }
             const int n_mov = nb - first;
-            if (n_mov <= 0) continue;
+            if (n_mov <= 0) { if (ts != s) HIP_TRY_C(c, hipStreamSynchronize(ts)); continue; }
             const int* knn_host = ws->host_knn;
             if (n0 > 0) {
                 // knn_match(query = frame-0 descriptors, train = frame-i descriptors, k = 2) for the whole batch  lib.rs:208-219
                 std::vector<int> cntv(nb);
                 for (int k = 0; k < nb; k++) cntv[k] = (int)kps[k].size();
-                HIP_TRY_C(c, hipMemcpyAsync(ws->counts.p, cntv.data(), sizeof(int) * nb, hipMemcpyHostToDevice, s));
+                HIP_TRY_C(c, hipMemcpyAsync(ws->counts.p, cntv.data(), sizeof(int) * nb, hipMemcpyHostToDevice, ts));
                 HIP_TRY_C(c, launch_knn2_hamming(desc0, n0, ws->desc.as<uint8_t>() + (size_t)first * MAX_KP * 32, 0,
-                                                 ws->knn.as<int>(), s, n_mov, ws->counts.as<int>() + first, MAX_KP));
-                HIP_TRY_C(c, hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, s));
-                HIP_TRY_C(c, hipStreamSynchronize(s));
+                                                 ws->knn.as<int>(), ts, n_mov, ws->counts.as<int>() + first, MAX_KP));
+                HIP_TRY_C(c, hipMemcpyAsync(ws->host_knn, ws->knn.p, (size_t)n_mov * n0 * 16, hipMemcpyDeviceToHost, ts));
+                HIP_TRY_C(c, hipStreamSynchronize(ts));
             }
             KPT(c, "lane: knn done");
             // C2/C3 on host threads: Lowe ratio, stable sort, truncate, point gather (lib.rs:221-264)
@@ -686,7 +696,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 if (!from_pts[m].empty()) { probs.push_back({from_pts[m].data(), to_pts[m].data(), (int)from_pts[m].size() / 2, nullptr}); owner.push_back(m); }
             std::vector<geom::HgOutcome> outc(probs.size());
             if (!probs.empty()) {
-                const int hst = geom::find_homography_batch(c, s, c->hg, probs.data(), (int)probs.size(), params->method,
+                const int hst = geom::find_homography_batch(c, ts, c->hg, probs.data(), (int)probs.size(), params->method,
                                                             params->ransac_reproj_threshold, outc.data());
                 if (hst) return (stk_status)hst;
             }
@@ -703,6 +713,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 R.n_inliers = o.n_inliers;
                 R.ok = true;
             }
+            if (ts != s && probs.empty()) HIP_TRY_C(c, hipStreamSynchronize(ts));         // (no homography call ended the batch on ts)
         }
         HIP_TRY_C(c, hipStreamSynchronize(s));
         return STK_OK;

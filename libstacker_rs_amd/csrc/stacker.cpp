@@ -66,6 +66,11 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
         hipStreamCreateWithFlags(&ctx->ecc_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->gate_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->gate_ev2, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+    {
+        int least = 0, greatest = 0;                          // (numerically lower = higher priority)
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        if (hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, greatest) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+    }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     if (hipHostMalloc((void**)&ctx->host_done, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
@@ -98,6 +103,7 @@ void stk_destroy(stk_ctx* ctx) {
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     if (ctx->ecc_stream2) (void)hipStreamDestroy(ctx->ecc_stream2);
+    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
