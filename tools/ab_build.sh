@@ -2,8 +2,8 @@
 # A/B build of the engine with ONE translation unit replaced: tools/ab_build.sh NAME path/to/variant.hip [extra flags]
 # -> libstacker_rs_amd/ab/libNAME.so (the other objects come from csrc/build). Use with STACKER_AMD_LIB=...
 set -e
+name=$1; src=$(realpath "$2"); shift 2              # (resolved before the cd below: a relative path is relative to the caller)
 cd "$(dirname "$0")/../libstacker_rs_amd/csrc"
-name=$1; src=$2; shift 2
 base=$(basename "$src")
 orig=${ORIG:-$base}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result -I. -I../../include"
