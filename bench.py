@@ -247,7 +247,7 @@ def main() -> None:
     # then measures a kernel that shares the device (its bytes / its time would overstate the rate) ----
     kp_sample = None
     if rank == 0 and api in ("keypoint", "hybrid") and args.profile_launches > 0:
-        lanes_cfg = 4
+        lanes_cfg = 3
         for kv in args.opt:
             if kv.split("=", 1)[0] == "kp_lanes":
                 lanes_cfg = int(kv.split("=", 1)[1])

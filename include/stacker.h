@@ -182,7 +182,7 @@ void        stk_host_free(void* p);
  *                        frames up to 1080p with >= 32 slots); 1: one sequence. Per-frame results do not depend on it
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter (0 = default: 2 for frames larger
  *                        than 1080p, 4 otherwise)
- *   "kp_lanes"           4 (default; 1..8): device-resident keypoint stacks of >= 16 frames are cut into this many runs of frames (at
+ *   "kp_lanes"           3 (default; 1..8): device-resident keypoint stacks of >= 16 frames are cut into this many runs of frames (at
  *                        least 8 each) that go through the pipeline side by side, the later ones on hidden helper contexts of
  *                        the same device, so that one run's kernels fill the other runs' host steps; the fold follows run by
  *                        run in stack order. 1: one pipeline. Per-frame results and the stacked image do not depend on it

@@ -62,7 +62,7 @@ struct stk_ctx {
     bool opt_orb_resize_tables = true; // ORB pyramid steps by the table-driven kernel (false: tables computed per tile, round 2's kernel; same bits)
     bool opt_orb_device_cull = true; // ORB: Harris cull and ordering of the short lists on the device (false: on the host pool); same keypoints
     bool opt_orb_patch_blur = true;  // ORB: the descriptor kernel blurs the window it reads (false: blur every level whole, then sample)
-    int opt_kp_lanes = 4;         // keypoint path on device-resident stacks: the stack is cut into this many runs of frames that go through the pipeline side by side (helper contexts), 1 = one pipeline
+    int opt_kp_lanes = 3;         // keypoint path on device-resident stacks: the stack is cut into this many runs of frames that go through the pipeline side by side (helper contexts), 1 = one pipeline
     int opt_kp_workers = 12;      // host threads for the per-frame host steps of the keypoint path (Harris cull, RANSAC)
     int opt_ecc_blocks = 0;       // total workgroups of one ECC iteration launch; 0 = 288 per frame in flight (see ecc_plan)
     int opt_ecc_ring = 1;         // column-walking ECC pass: frame-0 rows through the per-wave LDS ring (0: always gather from global memory)

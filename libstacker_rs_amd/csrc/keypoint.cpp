@@ -541,7 +541,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     results.assign(n, KpAlign{});
 
     // LANES (round 3). A third of a keypoint step is host work between device stages (Harris cull and ordering, match
-    // filter, RANSAC sampling): device-resident stacks are therefore cut into kp_lanes runs of frames (4; at least 8
+    // filter, RANSAC sampling): device-resident stacks are therefore cut into kp_lanes runs of frames (3; at least 8
     // frames each) that go through the whole pipeline side by side — the calling thread on this context, helper threads on
     // hidden contexts of the same device (own streams, events and workspaces: keypoint.cpp's code runs on them unchanged) —
     // so that one lane's kernels fill the other lanes' host gaps. Every frame is independent of the others (lib.rs:185-290
@@ -550,7 +550,8 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     // The device takes the lanes' FAST launches (each fills it) more or less one after the other, so the lanes drift apart
     // by themselves; what stays exposed is the LAST lane's host tail (cull -> BRIEF -> 2-NN -> filter -> RANSAC, ~0.75 ms
     // of latency for ~0.15 ms of kernels), which is why more, shorter lanes help up to 4-6 and the fold follows the lanes
-    // (`on_final`). 64 x 1080p: one pipeline 3.3-3.4 ms, 2 lanes 3.1-3.2, 4 lanes + following fold 2.8-2.9 ms per stack.
+    // (`on_final`). 64 x 1080p: one pipeline 3.3-3.4 ms, 2 lanes 3.1-3.2, 4 lanes + following fold 2.8-2.9 ms per stack; at the
+    // end of the round, with the tail shortened (device cull, 8-lane 2-NN, priority stream): 2 lanes 2.45, 3 lanes 2.36, 4 lanes 2.42.
     // Cutting a LANE into several ORB batches instead costs more than it hides (3.5-4.7 ms: every batch has its own syncs).
     struct RefShare {
         std::mutex m;

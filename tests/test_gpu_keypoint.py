@@ -277,7 +277,7 @@ def test_keypoint_lanes_do_not_change_results(stacker):
                 assert cur[0] == res[lanes][0] and np.array_equal(cur[1], res[lanes][1]) and cur[2] == res[lanes][2]
             res[lanes] = cur
     finally:
-        stacker.set_option("kp_lanes", 4)
+        stacker.set_option("kp_lanes", 3)
     assert res[1][0] == 2
     for lanes in (2, 3, 4):
         assert res[lanes][0] == res[1][0] and res[lanes][2] == res[1][2] and np.array_equal(res[lanes][3], res[1][3])
@@ -290,7 +290,7 @@ def test_keypoint_lanes_do_not_change_results(stacker):
             d, out, stats = stacker.keypoint_match(frames, kp, scale_down_width=400.0, return_stats=True)
             outs.append((d, out.cpu().numpy(), np.stack([s["warp"] for s in stats])))
     finally:
-        stacker.set_option("kp_lanes", 4)
+        stacker.set_option("kp_lanes", 3)
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
     with pytest.raises(Exception):
         stacker.set_option("kp_lanes", 9)
