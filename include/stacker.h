@@ -188,6 +188,8 @@ void        stk_host_free(void* p);
  *                        run in stack order. 1: one pipeline. Per-frame results and the stacked image do not depend on it
  *   "orb_resize_tables"  1 (default): ORB's pyramid steps read their bilinear coefficient tables from memory (computed once per
  *                        geometry); 0: every tile computes its own. Same bits either way
+ *   "kp_tail_priority"   1 (default): on device-resident stacks that run in several lanes, a lane's descriptor / 2-NN / homography launches
+ *                        go to a highest-priority stream (they queue behind the other lanes' large launches otherwise); 0: one stream
  *   "orb_device_cull"    1 (default): ORB's Harris cull (retainBest) and ordering run on the device; 0: on the host pool. Same keypoints
  *   "orb_patch_blur"     1 (default): ORB's 7x7 blur is computed by the descriptor kernel, for the 45 x 40 window around each kept
  *                        keypoint only; 0: every pyramid level is blurred whole first. Same bits either way

@@ -60,6 +60,7 @@ struct stk_ctx {
     int opt_ecc_chunk = 0;        // (iterate, solve) pairs between two polls of the completion counter; 0 = by frame size (stacker.cpp: ecc_run)
     int opt_profile_stride = 1;   // profile = 2: bracket every n-th ECC pixel pass with an event pair
     bool opt_orb_resize_tables = true; // ORB pyramid steps by the table-driven kernel (false: tables computed per tile, round 2's kernel; same bits)
+    bool opt_kp_tail_priority = true; // keypoint lanes: descriptor / 2-NN / homography launches on the highest-priority stream
     bool opt_orb_device_cull = true; // ORB: Harris cull and ordering of the short lists on the device (false: on the host pool); same keypoints
     bool opt_orb_patch_blur = true;  // ORB: the descriptor kernel blurs the window it reads (false: blur every level whole, then sample)
     int opt_kp_lanes = 3;         // keypoint path on device-resident stacks: the stack is cut into this many runs of frames that go through the pipeline side by side (helper contexts), 1 = one pipeline

@@ -623,9 +623,11 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
             // The lane's TAIL — descriptors, 2-NN, homography: microseconds of kernels between host steps — runs on a high-priority
             // stream: on the engine's stream these launches queue behind the other lanes' FAST and fold launches, which fill
             // the device (a 8 us model-scoring launch took 30-160 us to come back, a 58 us refinement 80-145): 2.41 -> 2.38 ms per
-            // 64 x 1080p stack, six A/B pairs in one call — the priority helps a launch onto the device, not through it. The blur-whole-
+            // 64 x 1080p stack, six A/B pairs in one call — the priority helps a launch onto the device, not through it. Only where
+            // other lanes compete: on a host-fed stack (one lane, the copy engines busy with uploads) the same stream COSTS 0.4 ms per
+            // batch (9.1 -> 12.4 ms per 64 x 1080p stack). The blur-whole-
             // level path keeps everything on s (the descriptors there depend on launches queued on s).
-            const hipStream_t ts = c->opt_orb_patch_blur && c->tail_stream ? c->tail_stream : s;
+            const hipStream_t ts = c->opt_orb_patch_blur && c->opt_kp_tail_priority && c->tail_stream && !host_fed && n_lanes > 1 ? c->tail_stream : s;
             if ((st = orb_run(c, ws, s, g, nb, threads, ws->desc.as<uint8_t>(), kps, ts))) return st;   // descriptors: queued on ts
             int first = 0;                                         // first moving frame of this batch
             if (b0 == 0) {
@@ -763,7 +765,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 if ((st = stk_create(ctx->device, &hk))) return fail(ctx, st, "keypoint lane: helper context creation failed");
                 (void)hipSetDevice(ctx->device);
             }
-            hk->opt_kp_workers = ctx->opt_kp_workers; hk->opt_orb_patch_blur = ctx->opt_orb_patch_blur; hk->opt_orb_resize_tables = ctx->opt_orb_resize_tables; hk->opt_orb_device_cull = ctx->opt_orb_device_cull; hk->opt_profile = ctx->opt_profile;
+            hk->opt_kp_workers = ctx->opt_kp_workers; hk->opt_orb_patch_blur = ctx->opt_orb_patch_blur; hk->opt_orb_resize_tables = ctx->opt_orb_resize_tables; hk->opt_orb_device_cull = ctx->opt_orb_device_cull; hk->opt_kp_tail_priority = ctx->opt_kp_tail_priority; hk->opt_profile = ctx->opt_profile;
             hk->opt_upload_batch = ctx->opt_upload_batch;
             timing_begin(hk);
             if (threads > 1) hk->shared_pool = ctx->shared_pool ? ctx->shared_pool : ctx->host_pool;

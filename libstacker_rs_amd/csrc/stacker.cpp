@@ -153,6 +153,7 @@ stk_status set_option_one(stk_ctx* ctx, const char* name, int64_t value) {
     else if (n == "profile_stride") { if (value < 1 || value > 1024) return fail(ctx, STK_INVALID_PARAMS, "profile_stride out of range"); ctx->opt_profile_stride = (int)value; }
     else if (n == "kp_lanes") { if (value < 1 || value > STK_MAX_KP_LANES) return fail(ctx, STK_INVALID_PARAMS, "kp_lanes must be 1..8"); ctx->opt_kp_lanes = (int)value; }
     else if (n == "orb_resize_tables") ctx->opt_orb_resize_tables = value != 0;
+    else if (n == "kp_tail_priority") ctx->opt_kp_tail_priority = value != 0;
     else if (n == "orb_device_cull") ctx->opt_orb_device_cull = value != 0;
     else if (n == "orb_patch_blur") ctx->opt_orb_patch_blur = value != 0;
     else if (n == "kp_workers") { if (value < 1 || value > 16) return fail(ctx, STK_INVALID_PARAMS, "kp_workers out of range"); ctx->opt_kp_workers = (int)value; }
