@@ -179,7 +179,7 @@ void        stk_host_free(void* p);
  *                        fire, the strips then fall back to the gather loop: stk_timing.ecc_ring_fallbacks); same bits
  *   "ecc_groups"         0 (default): by frame size; 2: the slots form two groups with their own (iterate, solve) launch sequences on
  *                        two streams, one group's solve and launch boundaries running under the other's iteration pass (pays for
- *                        frames up to 1080p with >= 32 slots); 1: one sequence. Per-frame results do not depend on it
+ *                        device-resident stacks of frames up to 1080p with >= 32 slots); 1: one sequence. Per-frame results do not depend on it
  *   "ecc_chunk"          (iterate, solve) pairs enqueued between two polls of the completion counter (0 = default: 2 for frames larger
  *                        than 1080p, 4 otherwise)
  *   "kp_lanes"           3 (default; 1..8): device-resident keypoint stacks of >= 16 frames are cut into this many runs of frames (at

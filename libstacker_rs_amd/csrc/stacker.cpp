@@ -327,9 +327,11 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
         // the fill / drain of its iteration launches run under the other half's iteration launch. The queue, the results and
         // the counters are shared (device-scope atomics); which slot a frame lands in never shows in its bits.
         // Measured (A/B in one call): 64 x 1080p 3.01 -> 2.88 ms per stack; 256 x 4K 56.7 -> 56.0 ms; 32 x 4K 7.66 -> 7.83 ms (two
-        // half-filled tails). Default (0 = auto): two groups for frames up to 1080p with at least 32 slots, else one. With
+        // half-filled tails). Default (0 = auto): two groups for frames up to 1080p with at least 32 slots when every template exists
+        // before the first launch, else one. With
         // per-launch event pairs (profile = 2) always one: a bracketed launch must not share the device with another.
-        const int want = ctx->opt_ecc_groups ? ctx->opt_ecc_groups : ((size_t)pl.w * pl.h <= (size_t)1920 * 1088 && pl.n_slots >= 32 ? 2 : 1);
+        // (not while frames are still arriving: host-fed, 64 x 1080p from pinned memory 9.2 -> 11.1 ms with two sequences)
+        const int want = ctx->opt_ecc_groups ? ctx->opt_ecc_groups : ((size_t)pl.w * pl.h <= (size_t)1920 * 1088 && pl.n_slots >= 32 && !feed ? 2 : 1);
         const int groups = (want >= 2 && pl.n_slots >= 8 && ctx->opt_profile < 2) ? 2 : 1;
         EccIterArgs ag[2] = {a, a};
         hipStream_t sg[2] = {ctx->stream, ctx->ecc_stream2};
