@@ -69,7 +69,10 @@ stk_status stk_create(int32_t device_id, stk_ctx** out) {
     {
         int least = 0, greatest = 0;                          // (numerically lower = higher priority)
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-        if (hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, greatest) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
+        if (hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();                           // no priorities on this device: the lanes then keep one stream
+            ctx->tail_stream = nullptr;
+        }
     }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
     for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return STK_HIP_ERROR; }
