@@ -452,7 +452,9 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
                 v[k] = make_uint4(b[0], b[1], b[2], b[3]);
             }
         }
-        for (int i = tid; i < FT_SH * FT_SW / 4; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0;
+        static_assert((FT_SH * FT_SW) % 8 == 0, "the score tile is cleared in 16- and 8-byte pieces");
+        for (int i = tid; i < FT_SH * FT_SW / 16; i += 256) reinterpret_cast<uint4*>(S)[i] = make_uint4(0, 0, 0, 0);
+        if (tid == 0 && (FT_SH * FT_SW) % 16) reinterpret_cast<uint2*>(S + (FT_SH * FT_SW / 16) * 16)[0] = make_uint2(0, 0);
 #pragma unroll
         for (int k = 0; k < NIT; k++) {
             const int i = tid + 256 * k;
@@ -486,7 +488,9 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
             const int sy = act ? i / ROW_DW : 0, dq = act ? i - sy * ROW_DW : 0;
             const uint32_t* R = reinterpret_cast<const uint32_t*>(T + (sy + 3) * FT_TW);
             const uint32_t c0 = R[dq];
-            const uint32_t cm = R[max(dq - 1, 0)], cp = R[min(dq + 1, ROW_DW - 1)];     // clamped reads feed invalid pixels only
+            // (dq - 1 = -1 and dq + 1 = ROW_DW read the neighbouring tile rows' edge dwords — rows 3 .. 36 of 40, inside T — and feed
+            // invalid pixels only: no clamps)
+            const uint32_t cm = R[dq - 1], cp = R[dq + 1];
             const uint32_t nn = reinterpret_cast<const uint32_t*>(T + sy * FT_TW)[dq];
             const uint32_t ss = reinterpret_cast<const uint32_t*>(T + (sy + 6) * FT_TW)[dq];
             const uint32_t ee = __builtin_amdgcn_alignbyte(cp, c0, 3);   // columns +3: bytes c0[3] cp[0] cp[1] cp[2]
