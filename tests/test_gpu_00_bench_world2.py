@@ -66,3 +66,18 @@ def test_bench_single_process_two_members():
     v = _json_line(r.stdout)
     _check_contract(v, 2)
     assert "ONE process" in v["config"]["parallelism"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_four_ranks_under_torchrun():
+    """Four ranks on the box's one GPU (the process guard allows six): two frames per rank, three of them without the reference
+    frame in their fold — the shard arithmetic, the double-buffered reduce and the counters behind the accumulator at N = 4."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "4", "--rehearse-on-one-gpu", "--workload", "ecc_small", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--host-fed-steps", "0"]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=840, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    v = _json_line(r.stdout)
+    assert v["n_gpus"] == 4 and v["config"]["frames_total"] == 8 and v["config"]["frames_per_gpu"] == 2
+    assert v["stages"]["frames_folded_last_step"] == 8 and v["stages"]["frames_dropped_last_step"] == 0
+    assert v["scaling"] == "strong" and v["value"] > 0
