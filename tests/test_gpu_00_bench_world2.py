@@ -81,3 +81,17 @@ def test_bench_four_ranks_under_torchrun():
     assert v["n_gpus"] == 4 and v["config"]["frames_total"] == 8 and v["config"]["frames_per_gpu"] == 2
     assert v["stages"]["frames_folded_last_step"] == 8 and v["stages"]["frames_dropped_last_step"] == 0
     assert v["scaling"] == "strong" and v["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_keypoint_workload():
+    """configs[1] cut over two ranks (32 frames each, every rank in three lanes; rank 1 folds without the reference frame):
+    all 64 frames arrive in the reduced sum."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "2", "--rehearse-on-one-gpu", "--workload", "keypoint_1080p", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--host-fed-steps", "0"]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=840, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    v = _json_line(r.stdout)
+    assert v["n_gpus"] == 2 and v["config"]["frames_total"] == 64 and v["config"]["frames_per_gpu"] == 32
+    assert v["stages"]["frames_folded_last_step"] == 64 and v["stages"]["frames_dropped_last_step"] == 0
