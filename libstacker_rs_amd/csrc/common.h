@@ -16,7 +16,7 @@ namespace stk {
 //
 //  * frames          interleaved BGR u8/u16/f32 as handed in (OpenCV Mat layout).
 //  * reference planes (ECC "input" = frame 0, shared by every frame of the stack):
-//        f32 planes  I (blurred grey), gx, gy  and an interleaved (gx, gy) copy, each (H + 2 REF_PAD) x ref_stride
+//        f32 planes  I (blurred grey), gx, gy, an interleaved (gx, gy) copy and an interleaved (I, gx, gy) copy, each (H + 2 REF_PAD) x ref_stride
 //        with a REF_PAD-pixel ZERO border on every side, so a bilinear footprint with BORDER_CONSTANT 0 is
 //        unconditional loads after clamping the integer coordinate to [-2, W] x [-2, H].
 //  * templates       one blurred-grey f32 plane per moving frame, row stride rounded up to a
@@ -34,6 +34,7 @@ struct RefPlanes {
     const float* gx;
     const float* gy;
     const float* gxy; // (gx, gy) interleaved, same padded geometry (2 floats per pixel)
+    const float* igg; // (I, gx, gy) interleaved, same padded geometry (3 floats per pixel): what the LDS ring of the column pass streams
     int stride;       // floats per padded row
     int w, h;
 };
@@ -190,7 +191,7 @@ hipError_t launch_grey_blur_batch(const void* const* ptrs_dev, const void* base,
                                   size_t stride_bytes, int ksize, float* out, int out_stride, size_t out_plane_stride, hipStream_t s);
 // blurred plane (stride in_stride) -> padded I/gx/gy planes
 hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
-                             int ref_stride, hipStream_t s);
+                             float* igg, int ref_stride, hipStream_t s);
 // variant: 3 = production kernels, 0 = direct cross-check version
 hipError_t launch_ecc_iter_col(const EccIterArgs& a, int motion, hipStream_t s);   // kernels_ecc_col.hip; a.units_q / units_r set
 hipError_t launch_ecc_iter(const EccIterArgs& a, int motion, int variant, hipStream_t s);

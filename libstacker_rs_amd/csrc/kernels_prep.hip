@@ -520,7 +520,7 @@ hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, si
 // ---- reference planes -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ref_planes_kernel(const float* __restrict__ b, int in_stride, int w, int h,
                                                          float* __restrict__ I, float* __restrict__ gx,
-                                                         float* __restrict__ gy, float* __restrict__ gxy, int rs) {
+                                                         float* __restrict__ gy, float* __restrict__ gxy, float* __restrict__ igg, int rs) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const float* row = b + (size_t)y * in_stride;
@@ -533,12 +533,13 @@ __global__ __launch_bounds__(256) void ref_planes_kernel(const float* __restrict
     gx[o] = vx;
     gy[o] = vy;
     *reinterpret_cast<float2*>(gxy + 2 * o) = make_float2(vx, vy);   // interleaved copy for the row-factorised ECC pass
+    igg[3 * o] = row[x]; igg[3 * o + 1] = vx; igg[3 * o + 2] = vy;     // (I, gx, gy): one LDS-DMA per row in the column pass
 }
 
 hipError_t launch_ref_planes(const float* blurred, int in_stride, int w, int h, float* I, float* gx, float* gy, float* gxy,
-                             int ref_stride, hipStream_t s) {
+                             float* igg, int ref_stride, hipStream_t s) {
     dim3 grid((w + 255) / 256, h);
-    ref_planes_kernel<<<grid, 256, 0, s>>>(blurred, in_stride, w, h, I, gx, gy, gxy, ref_stride);
+    ref_planes_kernel<<<grid, 256, 0, s>>>(blurred, in_stride, w, h, I, gx, gy, gxy, igg, ref_stride);
     return hipGetLastError();
 }
 

@@ -175,6 +175,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTim
 // ---------------------------------------------------------------------------------------------
 // ECC machinery shared by stk_ecc_match_shard and stk_find_transform_ecc
 // ---------------------------------------------------------------------------------------------
+constexpr int REF_PLANES = 8;     // I, gx, gy, (gx, gy) x 2 floats, (I, gx, gy) x 3 floats
 struct EccPlan {
     int w, h, n_templates, motion;
     int templ_row_stride;
@@ -246,9 +247,10 @@ static stk_status ecc_plan(stk_ctx* ctx, int w, int h, int n_templates, int moti
     nb = std::max(8, std::min(units, nb));
     nb = std::max(8, (nb / 8) * 8);                          // multiple of 8: XCD-aware block decode
     pl.nb = nb;
-    HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * 5 * sizeof(float)));
+    HIP_TRY(ctx->ref.reserve(pl.ref_plane_floats * REF_PLANES * sizeof(float) + 4096));   // (+ the overhang of a ring row behind the last plane)
     HIP_TRY(ctx->blur_tmp.reserve(pl.templ_plane_stride * sizeof(float)));
-    HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1) + 1024));
+    // (+ 4 rows: the column pass prefetches template rows up to three past the end of a strip, also behind the last row of the last frame)
+    HIP_TRY(ctx->templates.reserve(pl.templ_plane_stride * sizeof(float) * std::max(n_templates, 1) + 4 * (size_t)pl.templ_row_stride * sizeof(float) + 1024));
     HIP_TRY(ctx->slots.reserve(sizeof(EccSlot) * pl.n_slots));
     HIP_TRY(ctx->queue.reserve(sizeof(EccQueue)));
     HIP_TRY(ctx->results.reserve(sizeof(EccFrameResult) * std::max(n_templates, 1)));
@@ -263,13 +265,14 @@ static stk_status ecc_prepare_reference(stk_ctx* ctx, const EccPlan& pl, const v
     // the zero border is written once per geometry: ref_planes_kernel only ever writes the interior, so a stack of the same
     // size as the last one (every step of a shard's life) finds the border as it left it (171 MB of memset = 22 us at 4K)
     if (ctx->ref_zeroed_ptr != ctx->ref.p || ctx->ref_zeroed_w != pl.w || ctx->ref_zeroed_h != pl.h) {
-        HIP_TRY(hipMemsetAsync(ctx->ref.p, 0, pl.ref_plane_floats * 5 * sizeof(float), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->ref.p, 0, pl.ref_plane_floats * REF_PLANES * sizeof(float), ctx->stream));
         ctx->ref_zeroed_ptr = ctx->ref.p; ctx->ref_zeroed_w = pl.w; ctx->ref_zeroed_h = pl.h;
     }
     float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
     float* gxy = ctx->ref.as<float>() + 3 * pl.ref_plane_floats + 2 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
+    float* igg = ctx->ref.as<float>() + 5 * pl.ref_plane_floats + 3 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
     HIP_TRY(launch_ref_planes(ctx->blur_tmp.as<float>(), pl.templ_row_stride, pl.w, pl.h, base, base + pl.ref_plane_floats,
-                              base + 2 * pl.ref_plane_floats, gxy, pl.ref_stride, ctx->stream));
+                              base + 2 * pl.ref_plane_floats, gxy, igg, pl.ref_stride, ctx->stream));
     return STK_OK;
 }
 
@@ -291,7 +294,8 @@ static stk_status ecc_run(stk_ctx* ctx, const EccPlan& pl, EccCriteria crit, con
     EccIterArgs a{};
     const float* base = ctx->ref.as<float>() + (size_t)REF_PAD * pl.ref_stride + REF_PAD;
     const float* gxy = ctx->ref.as<float>() + 3 * pl.ref_plane_floats + 2 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
-    a.ref = RefPlanes{base, base + pl.ref_plane_floats, base + 2 * pl.ref_plane_floats, gxy, pl.ref_stride, pl.w, pl.h};
+    const float* igg = ctx->ref.as<float>() + 5 * pl.ref_plane_floats + 3 * ((size_t)REF_PAD * pl.ref_stride + REF_PAD);
+    a.ref = RefPlanes{base, base + pl.ref_plane_floats, base + 2 * pl.ref_plane_floats, gxy, igg, pl.ref_stride, pl.w, pl.h};
     a.templates = ctx->templates.as<float>();
     a.templ_plane_stride = pl.templ_plane_stride;
     a.templ_row_stride = pl.templ_row_stride;
