@@ -66,6 +66,12 @@ def main() -> None:
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the reduce goes through gloo/CPU "
                          "(checks the sharded code path, not a performance number)")
+    ap.add_argument("--files", default="", choices=["", "tiff", "pnm"],
+                    help="N = 1, ecc / keypoint workloads: ALSO time the reference's own call shape (a list of file paths, "
+                         "lib.rs:129-137, 702-710): the stack is written once to --files-dir as uncompressed TIFF or binary PNM, "
+                         "then stk_*_match_files decodes on host threads into pinned memory while the engine runs; never `value`")
+    ap.add_argument("--files-dir", default="/dev/shm", help="where --files writes the stack (tmpfs: the figure is decode + engine, not disk)")
+    ap.add_argument("--files-steps", type=int, default=2)
     ap.add_argument("--profile-launches", type=int, default=1,
                     help="0: no roofline sample; n >= 1: ONE extra step after the timed region (never inside it) with a HIP event "
                          "pair around every n-th ECC iteration launch (roofline.achieved)")
@@ -296,14 +302,18 @@ def main() -> None:
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "peak_achievable": round(stream_gbs, 1) if stream_gbs else None,
                 "peak_achievable_source": "scale_kernel (float4 stream, 4 B read + 4 B write per float of the W x H x 3 image), "
-                                          "best of 5 launches after the timed region, its own HIP-event timer",
-                "frac_of_achievable": round(achieved / stream_gbs, 4) if stream_gbs else None,
+                                          "best of 5 launches after the timed region, its own HIP-event timer; a yardstick for the "
+                                          "streaming kernels (fold, grey_blur), NOT for this one: its algorithmic bytes are served "
+                                          "from L2 / Infinity Cache for the most part (see traffic)",
                 "traffic": traffic, "traffic_source": tsrc,
                 "hbm_frac_of_traffic": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "avg_launch_ms": round(avg_ms, 5), "launches": launches, "launches_timed": sample["ecc_iter_timed"],
                 "timing": f"one extra step AFTER the timed region with a HIP event pair around every {stride}. launch, engine stream "
                           "(rocprofv3 --kernel-trace mean over ALL launches of the same command: profiles/); `value` is timed without event pairs",
                 "alg_bytes_per_launch": round(alg_bytes_total / launches, 1)}
+            valu = valu_roofline(args, world, "stk::ecc_iter_col_kernel<3>", px, sample, avg_ms)
+            if valu:
+                res["roofline"]["valu"] = valu
             kernels.append({"kernel": "ecc_iter_col_kernel<homography>", "bytes": "16 B/px/frame-iteration (algorithmic; cache-served in part)",
                             "GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(avg_ms * launches, 3)})
         # fold and FAST: from the single-pipeline sample step where there is one (keypoint, hybrid), else from the timed steps
@@ -383,6 +393,9 @@ def main() -> None:
                                "frac_of_pcie_ceiling": round((n_global * args.host_fed_steps / eh) / (n_global * args.host_fed_steps / (h2d_ms * 1e-3)), 3) if h2d_ms > 0 else None,
                                "note": "frames in pinned host memory; copy stream -> prep stream -> gated ECC queue; never `value`"}
             del host
+        # ---- the reference's own call shape: a list of file paths (decode on host threads inside the call) ----
+        if world == 1 and args.files and api in ("ecc", "keypoint"):
+            res["files"] = files_leg(args, st, frames, api, ecc_params, kp_params, n_global, W, H)
         # ---- CPU baseline: the oracle (a port of the reference's OpenCV/Rayon path) on host cores ----
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args, api, frames, W, H)
@@ -410,16 +423,46 @@ def result_header(args, value, elapsed, world, scaling, api, W, H, n_global, fpg
     }
 
 
-def pmc_traffic(args, world, kernel_prefix):
-    """HBM-side traffic per launch of the dominant kernel from the PMC passes of the SAME command (tools/profile_round.sh:
-    separate FETCH_SIZE / WRITE_SIZE passes, summary committed under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950 (calibrated in the same run on the float4 scale kernel AND on the byte-stream grey kernel),
-    WRITE_SIZE as reported. The summary records the SHA-256 of the kernel source it was taken with: a profile of an
-    older kernel is ignored (null) rather than reported."""
+# What a vector instruction costs a gfx950 SIMD (tools/valu_rates.hip, profiles/r04/valu_rates.txt; two or more waves per
+# SIMD): plain f32 add / mul / fma and simple 32-bit integer ops ~2.15 cycles per wave64 instruction, every packed-f32,
+# conversion, floor / fract, min / max, left shift, multiply, three-operand integer, DPP, compare ... ~4.3, v_rcp_f32 ~8.2.
+SLOT_CYCLES = 2.15
+PEAK_CLOCK_GHZ = 2.4
+N_SIMD = 256 * 4
+
+
+def valu_roofline(args, world, kernel_prefix, px, sample, avg_ms):
+    """The roof that bounds the ECC pass: vector-instruction ISSUE. From the committed counter passes of the same command
+    (profiles/r04/pmc_summary.json, pinned to the kernel sources like `traffic`): SQ_INSTS_VALU per launch -> instructions per
+    pixel and iteration; the static cost of the ring loop in issue slots (tools/isa_loops.py on the same sources; a packed or
+    half-rate instruction is two slots, v_rcp_f32 four) -> the fraction of the chip's issue slots the launch fills, at the
+    2.4 GHz peak clock and at the clock the chip held (GRBM_GUI_ACTIVE / 8 / duration)."""
+    pm, src = pmc_kernel(args, world, kernel_prefix)
+    if not pm or "SQ_INSTS_VALU_per_dispatch" not in pm:
+        return None
+    px_iter = px * sample["ecc_slot_iterations"] / max(sample["ecc_iter_launches"], 1)       # pixel-iterations per launch, this run
+    px_iter_pmc = pm.get("_px_iterations_per_dispatch") or px_iter
+    instr_per_px = pm["SQ_INSTS_VALU_per_dispatch"] * 64.0 / px_iter_pmc
+    slots_per_px = pm.get("_issue_slots_per_px")
+    out = {"instr_per_px": round(instr_per_px, 2), "source": src,
+           "slot": "one plain f32 / simple integer wave64 instruction = %.2f SIMD cycles (tools/valu_rates.hip)" % SLOT_CYCLES}
+    if slots_per_px:
+        slots_per_s = slots_per_px * px_iter / 64.0 / (avg_ms * 1e-3)             # wave-instruction slots the launch consumes per second
+        peak = N_SIMD * PEAK_CLOCK_GHZ * 1e9 / SLOT_CYCLES
+        out.update({"issue_slots_per_px": round(slots_per_px, 2), "slots_per_s": round(slots_per_s, 1), "slots_per_s_peak": round(peak, 1),
+                    "frac": round(slots_per_s / peak, 4)})
+        clk = pm.get("_clock_ghz_held")
+        if clk:
+            out.update({"clock_ghz_held": round(clk, 3), "frac_at_held_clock": round(slots_per_s / (N_SIMD * clk * 1e9 / SLOT_CYCLES), 4)})
+    return out
+
+
+def pmc_kernel(args, world, kernel_prefix):
+    """The committed PMC summary entry of a kernel, or (None, reason) when it was taken with other kernel sources."""
     import hashlib
     if args.workload != "ecc_4k" or world != 1 or args.opt or args.ecc_slots or args.frames_per_gpu:
         return None, None
-    for rnd in ("r03",):
+    for rnd in ("r04", "r03"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
         try:
             allk = json.load(open(path))
@@ -430,11 +473,77 @@ def pmc_traffic(args, world, kernel_prefix):
                 h.update(open(os.path.join(ROOT, "libstacker_rs_amd", "csrc", name), "rb").read())
             if want is None or want != h.hexdigest():
                 return None, f"profiles/{rnd}/pmc_summary.json is from older ECC sources: ignored"
-            return round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1), \
-                f"rocprofv3 --pmc, same command (profiles/{rnd}/pmc_summary.json)"
+            return pm, f"rocprofv3 --pmc, same command (profiles/{rnd}/pmc_summary.json)"
         except Exception:
             continue
     return None, None
+
+
+def pmc_traffic(args, world, kernel_prefix):
+    """HBM-side traffic per launch of the dominant kernel from the PMC passes of the SAME command (tools/profile_round.sh:
+    separate FETCH_SIZE / WRITE_SIZE passes, summary committed under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950 (calibrated in the same run on the float4 scale kernel AND on the byte-stream grey kernel),
+    WRITE_SIZE as reported. The summary records the SHA-256 of the kernel source it was taken with: a profile of an
+    older kernel is ignored (null) rather than reported."""
+    pm, src = pmc_kernel(args, world, kernel_prefix)
+    if not pm:
+        return None, src
+    return round(2 * pm["FETCH_SIZE_bytes_per_dispatch"] + pm["WRITE_SIZE_bytes_per_dispatch"], 1), src
+
+
+def files_leg(args, st, frames, api, ecc_params, kp_params, n_global, W, H):
+    """ecc_match(files, ...) / keypoint_match(files, ...) as the reference is called (lib.rs:129-137, 702-710): the synthetic
+    stack is written ONCE to tmpfs, then every step decodes it again (a pool of host threads, straight into pinned memory)
+    while the engine uploads, prepares and aligns the frames that have arrived."""
+    import shutil
+    import struct
+    import tempfile
+    import numpy as np
+    d = tempfile.mkdtemp(prefix="stk_bench_", dir=args.files_dir)
+    try:
+        paths, nbytes = [], 0
+        tw = time.perf_counter()
+        for i in range(frames.shape[0]):
+            a = np.ascontiguousarray(frames[i].cpu().numpy()[..., ::-1])          # BGR -> RGB on disk
+            path = os.path.join(d, "f%04d.%s" % (i, "tif" if args.files == "tiff" else "ppm"))
+            with open(path, "wb") as f:
+                if args.files == "pnm":
+                    f.write(("P6\n%d %d\n255\n" % (W, H)).encode())
+                else:                                                             # baseline TIFF: little-endian, uncompressed, one strip
+                    n_tags, ifd_ofs = 10, 8
+                    bps_ofs = ifd_ofs + 2 + 12 * n_tags + 4
+                    data_ofs = bps_ofs + 8
+                    tag = lambda t, typ, cnt, val: struct.pack("<HHII", t, typ, cnt, val)
+                    ifd = struct.pack("<H", n_tags) + tag(256, 4, 1, W) + tag(257, 4, 1, H) + tag(258, 3, 3, bps_ofs) + tag(259, 3, 1, 1) \
+                        + tag(262, 3, 1, 2) + tag(273, 4, 1, data_ofs) + tag(277, 3, 1, 3) + tag(278, 4, 1, H) + tag(279, 4, 1, a.nbytes) \
+                        + tag(284, 3, 1, 1) + struct.pack("<I", 0)
+                    f.write(b"II" + struct.pack("<HI", 42, ifd_ofs) + ifd + struct.pack("<HHHH", 8, 8, 8, 0))
+                f.write(a.tobytes())
+            nbytes += os.path.getsize(path)
+            paths.append(path)
+        write_s = time.perf_counter() - tw
+
+        def run():
+            if api == "ecc":
+                return st.ecc_match_files(paths, ecc_params)
+            return st.keypoint_match_files(paths, kp_params)
+        run()                                                                     # warm-up: pinned block, page cache
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.files_steps):
+            run()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.files_steps
+        workers = min(len(paths) - 1, max(1, min(os.cpu_count() or 1, 16)))
+        return {"value": round(n_global / el, 3), "unit": "frames/s", "steps": args.files_steps, "ms_per_step": round(el * 1e3, 3),
+                "format": "uncompressed RGB TIFF, one strip" if args.files == "tiff" else "binary PPM (P6)",
+                "file_MB": round(nbytes / len(paths) / 1e6, 2), "decode_MBps": round(nbytes / el / 1e6, 1),
+                "decode_threads": workers, "host_cores": os.cpu_count(), "dir": args.files_dir, "written_in_s": round(write_s, 1),
+                "note": "stk_%s_match_files: decode (host threads, into one page-locked block) + H2D + the whole path per step, "
+                        "files in tmpfs; never `value`" % ("ecc" if api == "ecc" else "keypoint")}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(args, api, frames, W, H):

@@ -7,7 +7,9 @@
 // destination pixel, keeps its three accumulator channels in registers across ALL frames of the
 // launch and touches HBM for: the source taps (u8: ~3 B/px/frame, gathered, L2-friendly because the
 // maps are near-identity) + one 12-byte accumulator read + one 12-byte accumulator write.
-// HBM-bound; no LDS needed for the gather (footprints of neighbouring lanes overlap in L1/L2).
+// NOT HBM-bound: 3 bytes per pixel and frame carry ~65 vector instructions (~108 issue slots at gfx950's rates, twelve
+// byte conversions alone are 24: tools/valu_rates.hip) — the vector pipe is the limit. No LDS needed for
+// the gather (footprints of neighbouring lanes overlap in L1/L2).
 #include "common.h"
 
 namespace stk {
@@ -482,7 +484,8 @@ hipError_t launch_warp_frames_from_ecc(const EccFrameResult* results, const void
 
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
     dim3 grid((a.dw + 63) / 64, (a.dh + 3) / 4);
-    if (depth == 8 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 &&
+    // (sh >= 2: the kernel's interior bound is (unsigned)(sh - 2); a one-row frame takes the generic kernel)
+    if (depth == 8 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 && a.sh >= 2 &&
         (size_t)a.sw * a.sh * 3 >= 16 && a.src_stride * (size_t)a.sh < ((size_t)1 << 31) && a.src_stride < (1u << 23) && a.sh < (1 << 23)) {
         const int v = a.tune;                       // tuning: bits 0-1 tile shape, bits 4-5 frames in flight
 #define STK_U8C3(WX, WU)                                                                                   \

@@ -62,20 +62,28 @@ def ecc_stack_error(out, ref, frames, warps, alpha=1.0 / 255.0):
     return float(rel.max()), float(floor.max())
 
 
-def assert_ecc_stack_close(out, ref, frames, warps, alpha=1.0 / 255.0, label="", iters=None, iters_ref=None):
+ECC_FLOOR_FACTOR = 1.3
+
+
+def assert_ecc_stack_close(out, ref, frames, warps, alpha=1.0 / 255.0, label="", iters=None, iters_ref=None, bar=1e-4):
     """North-star bar for the end-to-end ECC stack: MAX relative error <= 1e-4 over the interior, or — on frames wide
-    enough that one f32 ulp of the warp matrix moves a sample by more than that is worth (x ~ 2000: 1.2e-4 px) — <= 3 x the
-    oracle's own 1-ulp floor. Prints both numbers.
-    Only when the two sides stopped a different number of iterations apart (|rho - last_rho| within round-off of eps at
-    the stop; the callers allow +-1) is the comparison between two different points of the same trajectory: then the last
-    step (<= 0.05 px) bounds the image difference instead, and that is what is asserted."""
+    enough that one f32 ulp of the warp matrix moves a sample by more than that is worth (x ~ 2000: 1.2e-4 px) — <= 1.3 x
+    the oracle's own 1-ulp floor (round 4; it was 3 x. Measured: 1.24 x the floor at 1080p, 2.1e-4 against 1.7e-4, and
+    0.79 x at 4K, 4.8e-4 against 6.1e-4: 1.25 would leave the 1080p stack 1 % of room).
+    `iters` / `iters_ref`, when given, must be EQUAL: the test stacks are seeded and the engine is deterministic, so a
+    count that differs from the oracle's is a regression, not a tolerance (round 3 switched to a 0.05 bar then).
+    Prints the error under both readings of "relative": per pixel, |a - b| / max(|b|, 1e-3) (the one asserted),
+    and against the image's range, max |a - b| / max |b|. `bar`: 1e-4 (the north star) unless the caller states another."""
     err, floor = ecc_stack_error(out, ref, frames, warps, alpha)
-    same_stop = iters is None or all(int(a) == int(b) for a, b in zip(iters, iters_ref))
-    print("%s ecc stack: max rel %.3e (oracle 1-ulp floor %.3e, same iteration counts: %s)" % (label, err, floor, same_stop))
-    if same_stop:
-        assert err <= max(1e-4, 3.0 * floor), (err, floor)
-    else:
-        assert err <= 0.05, err       # one ECC step of <= 0.05 px across a unit-contrast edge, folded 1/n
+    if iters is not None:
+        assert [int(a) for a in iters] == [int(b) for b in iters_ref], ("iteration counts differ from the oracle's", list(iters), list(iters_ref))
+    n = len(frames)
+    m = interior_mask(ref.shape[:2], [warps[i] for i in range(1, n)])
+    d = np.abs(np.asarray(out, np.float64) - ref)[m]
+    range_rel = float(d.max() / np.abs(ref).max())
+    print("%s ecc stack: max |a-b|/max(|b|,1e-3) %.3e (oracle 1-ulp floor %.3e = %.2f x), max |a-b|/max|b| %.3e"
+          % (label, err, floor, err / max(floor, 1e-30), range_rel))
+    assert err <= max(bar, ECC_FLOOR_FACTOR * floor), (err, floor)
     return err, floor
 
 

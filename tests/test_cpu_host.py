@@ -3,6 +3,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -338,3 +339,25 @@ def test_imread_jpeg_through_runtime_libjpeg(tmp_path):
     read("hdr_only.jpg", expect=4)
     (tmp_path / "empty.jpg").write_bytes(b"")
     read("empty.jpg", expect=4)
+
+
+def test_rust_ffi_is_generated_from_the_header():
+    """rust/src/amd_ffi.rs (the `extern "C"` block, structs and constants of the Rust crate) is what tools/gen_rust_ffi.py
+    prints for include/stacker.h today, and it declares every symbol of the header — the Rust side cannot be compiled in
+    this container (no rustc), so this is the check that it has not drifted from the ABI."""
+    import re
+    import subprocess
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py")], capture_output=True, text=True, check=True).stdout
+    committed = open(os.path.join(ROOT, "rust", "src", "amd_ffi.rs")).read()
+    assert gen == committed, "run: python tools/gen_rust_ffi.py > rust/src/amd_ffi.rs"
+    declared = sorted(re.findall(r"pub fn (stk_\w+)\(", committed))
+    assert declared == _header_symbols()
+    # the hand-written half only calls what the generated half declares
+    used = set(re.findall(r"\b(stk_[a-z0-9_]+)\(", open(os.path.join(ROOT, "rust", "src", "amd.rs")).read()))
+    assert used and used <= set(declared), used - set(declared)
+    # struct layouts: same field order as the ctypes mirror (whose sizes test_struct_layouts_match_the_header checks against C)
+    from libstacker_rs_amd import _ffi
+    for cname, ctype in (("stk_keypoint_params", _ffi.KeypointParams), ("stk_ecc_params", _ffi.EccParams), ("stk_frames", _ffi.Frames),
+                         ("stk_image_f32", _ffi.ImageF32)):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % cname, committed, re.S).group(1)
+        assert re.findall(r"pub (\w+):", body) == [f[0] for f in ctype._fields_], cname

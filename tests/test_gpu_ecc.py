@@ -20,9 +20,9 @@ def test_find_transform_ecc_homography_matches_oracle(stacker, small_stack):
         W, rho, its = stacker.find_transform_ecc(gi, g0, np.eye(3), PARAMS)
         rc, Wo, rho_o, its_o = oracle.find_transform_ecc(gi, g0, np.eye(3), oracle.MOTION_HOMOGRAPHY, 5000, 1e-5, 5)
         assert rc == 0
-        # <= 0.05 px corner displacement vs the oracle, iteration count within +-1
+        # <= 0.05 px corner displacement vs the oracle, the same iteration count
         assert synth.corner_error(W, Wo, 320, 240) <= 0.05
-        assert abs(its - its_o) <= 1
+        assert its == its_o
         assert abs(rho - rho_o) <= 1e-5
         assert synth.corner_error(W, G[i], 320, 240) <= 0.25      # vs generator ground truth
 
@@ -131,7 +131,7 @@ def test_direct_variant_agrees_with_production(stacker, small_stack):
     finally:
         stacker.set_option("ecc_variant", 3)
     for a, d in zip(s0[1:], s3[1:]):
-        assert abs(a["iterations"] - d["iterations"]) <= 1
+        assert a["iterations"] == d["iterations"]
         assert synth.corner_error(a["warp"], d["warp"], 320, 240) <= 0.02
     # a caller-supplied start whose m22 is not 1 takes the direct kernel and must leave the option as it was
     g0 = oracle.grey(frames[0])
@@ -295,7 +295,7 @@ def test_ecc_match_scaling_down_matches_oracle(stacker):
         ref, warps, iters = oracle.ecc_match(list(frames), motion=omotion, scale_down_width=240.0)
         for i in (1, 2):
             assert synth.corner_error(stats[i]["warp"], warps[i], 640, 480) <= 0.1      # 0.05 px at half size
-            assert abs(stats[i]["iterations"] - int(iters[i])) <= 1
+            assert stats[i]["iterations"] == int(iters[i])
         assert_ecc_stack_close(out, ref, frames, [w[:2] if motion != MotionType.Homography else w for w in warps], label="scaled %s" % motion.name,
                                iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
     for i in (1, 2):                                             # full-size truth (homography run)
@@ -344,7 +344,7 @@ def test_ecc_match_f32_frames(stacker, small_stack):
     ref, warps, iters = oracle.ecc_match(f32, max_count=5000, epsilon=1e-5, gauss_filt_size=5)
     for i in (1, 2):
         assert synth.corner_error(stats[i]["warp"], warps[i], 320, 240) <= 0.05
-        assert abs(stats[i]["iterations"] - int(iters[i])) <= 1
+        assert stats[i]["iterations"] == int(iters[i])
     assert_ecc_stack_close(out, ref, f32, warps, label="f32 frames", iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
     # 16-bit frames: the reference's grey is 16UC1, which findTransformECC rejects -> OpenCvError
     with pytest.raises(OpenCvError):

@@ -178,9 +178,13 @@ def test_files_are_decoded_in_parallel_into_pinned_memory(stacker, tmp_path):
     if not os.path.exists(py):
         return
     np.save(tmp_path / "stack.npy", fr[:6])
-    code = ("import numpy as np, sys\\nfrom PIL import Image\\nd = sys.argv[1]\\na = np.load(d + '/stack.npy')\\n"
-            "for i, f in enumerate(a):\\n    Image.fromarray(f[..., ::-1]).save(d + '/j%02d.jpg' % i, quality=95, subsampling=0)\\n")
-    if subprocess.run([py, "-c", code, str(tmp_path)]).returncode != 0:
+    # (round 4: the snippet used to carry literal backslash-n sequences, was a SyntaxError for the side interpreter, and this
+    # half of the test returned early without ever running)
+    code = ("import numpy as np, sys\nfrom PIL import Image\nd = sys.argv[1]\na = np.load(d + '/stack.npy')\n"
+            "for i, f in enumerate(a):\n    Image.fromarray(f[..., ::-1]).save(d + '/j%02d.jpg' % i, quality=95, subsampling=0)\n")
+    r = subprocess.run([py, "-c", code, str(tmp_path)], capture_output=True)
+    if r.returncode != 0:
+        assert b"No module named" in r.stderr, r.stderr          # no Pillow in that interpreter: nothing to write JPEGs with
         return
     jpaths = [tmp_path / ("j%02d.jpg" % i) for i in range(6)]
     decoded = [stacker.imread(p) for p in jpaths]

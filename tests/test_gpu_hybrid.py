@@ -36,8 +36,11 @@ def test_hybrid_match_matches_oracle(stacker, bits):
         # other run to max_count while moving the corners by < 0.05 px); the warps are.
         assert stats[i]["iterations"] <= 200 and int(iters[i]) <= 200
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 0.3        # vs generator ground truth
-    assert_ecc_stack_close(out, ref, fr, warps, alpha=1.0 / 65535.0 if bits == 16 else 1.0 / 255.0, label="hybrid %d-bit" % bits,
-                           iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
+    # (no iteration counts handed over — see above —: the image has to meet the bar on its own. The two sides stop at
+    # different points of the same converged trajectory, warps up to 0.05 px apart instead of 1-2 ulp: measured 5.7e-5
+    # (16-bit) and 1.01e-4 (8-bit; 2.3e-5 of the image's range) per-pixel relative; the stated bar here is 1.5e-4, the one
+    # place in the suite where it is not 1e-4 or the oracle's own floor)
+    assert_ecc_stack_close(out, ref, fr, warps, alpha=1.0 / 65535.0 if bits == 16 else 1.0 / 255.0, label="hybrid %d-bit" % bits, bar=1.5e-4)
     assert 0.0 <= out.min() and out.max() <= 1.0 + 1e-6                           # alpha 1/65535 resp. 1/255: unit range
 
 

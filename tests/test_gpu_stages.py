@@ -207,6 +207,10 @@ def test_warp_fast_paths_equal_the_generic_kernel_everywhere_also_for_non_finite
     an affine map with a NaN translation, and matrices whose W range is tested per frame on the host (round 3)."""
     for w in (203, 204):                                        # odd rows (8-byte gathers) and dword-aligned rows (12-byte windows)
         _fast_paths_everywhere(stacker, dtype, 131, w)
+    # frames of one and two rows (ADVICE r3: the u8 launcher took the fast kernel for sh == 1, whose interior bound
+    # (unsigned)(sh - 2) then wraps and lets every pixel — the non-finite sentinel too — gather unclamped)
+    for h in (1, 2):
+        _fast_paths_everywhere(stacker, dtype, h, 204)
 
 
 def _fast_paths_everywhere(stacker, dtype, h, w):
