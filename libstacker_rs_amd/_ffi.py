@@ -32,6 +32,10 @@ class Frames(C.Structure):
                 ("location", C.c_int32), ("row_stride_bytes", C.c_size_t)]
 
 
+class FrameGeometry(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("row_stride_bytes", C.c_size_t)]
+
+
 class ImageF32(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
                 ("channels", C.c_int32), ("location", C.c_int32), ("row_stride_bytes", C.c_size_t)]
@@ -68,6 +72,8 @@ SIGNATURES = {
     "stk_set_option": (c_status, [C.c_void_p, C.c_char_p, C.c_int64]),
     "stk_keypoint_match": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(KeypointParams), C.c_float,
                                       C.POINTER(ImageF32), C.POINTER(C.c_int32), C.POINTER(FrameStats)]),
+    "stk_keypoint_match_mixed": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(FrameGeometry), C.POINTER(KeypointParams),
+                                            C.POINTER(ImageF32), C.POINTER(C.c_int32), C.POINTER(FrameStats)]),
     "stk_ecc_match": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(EccParams), C.c_float,
                                  C.POINTER(ImageF32), C.POINTER(FrameStats)]),
     "stk_ecc_match_shard": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(EccParams), C.c_float, C.c_int32,

@@ -296,8 +296,32 @@ class Stacker:
         self._check(st)
         return (out, self._stats_list(stats, m.n)) if return_stats else out
 
+    def _keypoint_match_mixed(self, frames, params: KeyPointMatchParameters, return_stats: bool):
+        """Frames of differing size (host arrays, HxWx3 u8): ORB at each frame's own size, every frame warped into the FIRST
+        frame's size, as the reference does (lib.rs:166, 200-204, 290-299) — stk_keypoint_match_mixed."""
+        arrs = [np.ascontiguousarray(f.cpu().numpy() if _is_torch(f) else f) for f in frames]
+        for a in arrs:
+            if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+                raise OpenCvError("ORB: 8-bit BGR frames expected")
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        geo = (_ffi.FrameGeometry * n)(*[_ffi.FrameGeometry(a.shape[1], a.shape[0], 0) for a in arrs])
+        h0, w0 = arrs[0].shape[:2]
+        fr = _ffi.Frames(C.cast(ptrs, C.POINTER(C.c_void_p)), n, w0, h0, 3, 8, HOST, 0)
+        out = np.empty((h0, w0, 3), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w0, h0, 3, HOST, 0)
+        stats = (_ffi.FrameStats * n)()
+        dropped = C.c_int32(0)
+        p = params._c()
+        self._check(self._lib.stk_keypoint_match_mixed(self._h, C.byref(fr), geo, C.byref(p), C.byref(img), C.byref(dropped), stats))
+        return (dropped.value, out, self._stats_list(stats, n)) if return_stats else (dropped.value, out)
+
     def keypoint_match(self, files, params: KeyPointMatchParameters, scale_down_width: Optional[float] = None,
                        return_stats: bool = False):
+        if isinstance(files, (list, tuple)) and len({tuple(f.shape) for f in files}) > 1:
+            if scale_down_width:
+                raise NotImplementedYet("scale_down_width on frames of differing size")
+            return self._keypoint_match_mixed(files, params, return_stats)
         m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")

@@ -107,12 +107,13 @@ using stk::WarpFrame;
 size_t frame_row_bytes(const stk_frames* f);
 stk_status resolve_frames(stk_ctx* ctx, const stk_frames* f, std::vector<const void*>& dev);
 stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr);
+// (w, h): the SOURCE frames' size; (dw, dh): the accumulator's, 0 = the same (a stack of one geometry)
 stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
                      size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
-                     int is_affine, float* acc, size_t acc_stride_floats, int accumulate);
+                     int is_affine, float* acc, size_t acc_stride_floats, int accumulate, int dw = 0, int dh = 0);
 stk_status warp_fold_enqueue(stk_ctx* ctx, int n_frames, int depth, int w, int h, int cn, size_t src_row_bytes, double alpha,
                              int border_mode, const double* border_value, int is_affine, float* acc, size_t acc_stride_floats,
-                             int accumulate, int first_frame = 0);
+                             int accumulate, int first_frame = 0, int dw = 0, int dh = 0);
 void make_warp_frame(WarpFrame& wf, const void* src, const double* M, int is_affine);
 stk_status image_check(stk_ctx* ctx, const stk_image_f32* im, int w, int h, int c);
 size_t image_stride_floats(const stk_image_f32* im);

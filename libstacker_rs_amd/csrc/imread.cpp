@@ -505,8 +505,11 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
 // decoded here by a pool of host threads as well, straight into ONE page-locked block (frame i at i * frame_bytes), so
 // that the host-fed pipeline behind the frame-based entry points moves them by DMA at link rate. Frame 0 is decoded first
 // (it fixes the geometry every other file must match, lib.rs:166).
+// `on_mixed_sizes`: what to do when the files decode to frames of differing SIZE (same channels and depth). The reference's
+// keypoint path takes such a stack (every frame is read on its own, lib.rs:200-204, and warped into the first frame's
+// size, lib.rs:290-299); its ECC path fails on it in cv::add (lib.rs:809). Null: the mismatch is reported as that failure.
 template <typename Call>
-stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call call) {
+stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call call, const std::function<stk_status()>* on_mixed_sizes = nullptr) {
     if (!ctx) return STK_INVALID_PARAMS;
     if (n <= 0 || !paths) return fail(ctx, STK_NOT_ENOUGH_FILES, "Not enough files");      // lib.rs:155-157, 725-727
     Pnm first;
@@ -533,6 +536,7 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
     // different frames overlap. The first failure (lowest index) is the one reported, like a sequential loop.
     const int workers = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, (size_t)std::max(n - 1, 1)});
     std::atomic<int> next{1};
+    std::atomic<bool> size_mismatch{false};
     std::mutex em;
     std::condition_variable ecv;
     std::vector<char> state(n, 0);                       // 0 pending, 1 decoded, 2 failed (guarded by em)
@@ -548,8 +552,14 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
             std::vector<unsigned char> file;
             Pnm p;
             stk_status s2 = load_image(&local, paths[i], file, p);
-            if (!s2 && (p.w != first.w || p.h != first.h || p.cn != first.cn || p.depth != first.depth))
-                s2 = fail(&local, STK_INVALID_PARAMS, std::string("'") + paths[i] + "' differs in size or type from the first frame");
+            if (!s2 && (p.cn != first.cn || p.depth != first.depth))
+                s2 = fail(&local, STK_BACKEND_ERROR, std::string("'") + paths[i] + "' differs in size or type from the first frame (channels / depth)");
+            else if (!s2 && (p.w != first.w || p.h != first.h)) {
+                size_mismatch.store(true);
+                s2 = fail(&local, STK_BACKEND_ERROR, std::string("'") + paths[i] + "' differs in size or type from the first frame (" +
+                                  std::to_string(p.w) + " x " + std::to_string(p.h) + " against " + std::to_string(first.w) + " x " +
+                                  std::to_string(first.h) + "): cv::add needs one size (lib.rs:809)");
+            }
             if (!s2) place(i, file, p);
             {
                 std::lock_guard<std::mutex> lk(em);
@@ -588,8 +598,52 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
     st = call(&fr);
     ctx->frame_gate = nullptr;
     for (auto& t : pool.threads) t.join();
+    if (err_status && size_mismatch.load() && on_mixed_sizes) return (*on_mixed_sizes)();   // (an unreadable file shows up there again)
     if (err_status) return fail(ctx, err_status, err_msg);   // a file that could not be decoded outranks whatever the engine made of it
     return st;
+}
+
+// keypoint_match on files that decode to frames of differing size: every file decoded into a buffer of its own (a pool of
+// host threads), then stk_keypoint_match_mixed on the host frames
+stk_status keypoint_files_mixed(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_keypoint_params* params, float scale_down_width,
+                                stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats) {
+    if (scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "scale_down_width on frames of differing size");
+    std::vector<std::vector<unsigned char>> pix(n);
+    std::vector<stk_frame_geometry> geo(n);
+    std::vector<Pnm> heads(n);
+    std::vector<stk_status> sts(n, STK_OK);
+    std::vector<std::string> msgs(n);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        stk_ctx local;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            std::vector<unsigned char> file;
+            sts[i] = load_image(&local, paths[i], file, heads[i]);
+            if (sts[i]) { msgs[i] = local.err; continue; }
+            const Pnm& p = heads[i];
+            if (p.data_ofs == (size_t)-1) pix[i].swap(file);
+            else { pix[i].resize((size_t)p.w * p.h * p.cn * (p.depth / 8)); pnm_decode(file.data() + p.data_ofs, p, pix[i].data()); }
+            geo[i] = stk_frame_geometry{p.w, p.h, 0};
+        }
+    };
+    {
+        const int workers = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, (size_t)n});
+        struct Joiner { std::vector<std::thread> t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } pool;
+        try { for (int t = 1; t < workers; t++) pool.t.emplace_back(work); } catch (const std::exception&) {}
+        work();
+    }
+    for (int i = 0; i < n; i++) if (sts[i]) return fail(ctx, sts[i], msgs[i]);
+    for (int i = 1; i < n; i++)
+        if (heads[i].cn != heads[0].cn || heads[i].depth != heads[0].depth)
+            return fail(ctx, STK_BACKEND_ERROR, std::string("'") + paths[i] + "' differs in type from the first frame (channels / depth)");
+    std::vector<const void*> ptrs(n);
+    for (int i = 0; i < n; i++) ptrs[i] = pix[i].data();
+    stk_frames fr{};
+    fr.data = ptrs.data(); fr.n = n; fr.width = heads[0].w; fr.height = heads[0].h; fr.channels = heads[0].cn; fr.depth = heads[0].depth;
+    fr.location = STK_HOST;
+    return stk_keypoint_match_mixed(ctx, &fr, geo.data(), params, out, dropped, stats);
 }
 
 }  // namespace
@@ -616,7 +670,8 @@ stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacit
 
 stk_status stk_keypoint_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_keypoint_params* params,
                                     float scale_down_width, stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats) {
-    return match_files(ctx, paths, n, [&](const stk_frames* fr) { return stk_keypoint_match(ctx, fr, params, scale_down_width, out, dropped, stats); });
+    const std::function<stk_status()> mixed = [&]() { return keypoint_files_mixed(ctx, paths, n, params, scale_down_width, out, dropped, stats); };
+    return match_files(ctx, paths, n, [&](const stk_frames* fr) { return stk_keypoint_match(ctx, fr, params, scale_down_width, out, dropped, stats); }, &mixed);
 }
 
 stk_status stk_ecc_match_files(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_ecc_params* params,

@@ -440,14 +440,14 @@ static const char* ecc_status_message(int st) {
 // fold frames into `sum` (device, tightly packed or strided) through their warps
 stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w, int h, int cn,
                             size_t src_row_bytes, double alpha, int border_mode, const double* border_value,
-                            int is_affine, float* acc, size_t acc_stride_floats, int accumulate) {
+                            int is_affine, float* acc, size_t acc_stride_floats, int accumulate, int dw, int dh) {
     if (wf.empty()) return STK_OK;
-    // per frame, once: the flags the fast kernels branch on (common.h: warp_frame_flags)
-    for (WarpFrame& f : wf) f.flags = warp_frame_flags(f.src, f.M, src_row_bytes, w, h, is_affine);
+    // per frame, once: the flags the fast kernels branch on (common.h: warp_frame_flags; the rectangle is the DESTINATION's)
+    for (WarpFrame& f : wf) f.flags = warp_frame_flags(f.src, f.M, src_row_bytes, dw > 0 ? dw : w, dh > 0 ? dh : h, is_affine);
     HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * wf.size()));
     HIP_TRY(hipMemcpyAsync(ctx->warpframes.p, wf.data(), sizeof(WarpFrame) * wf.size(), hipMemcpyHostToDevice, ctx->stream));
     stk_status st = warp_fold_enqueue(ctx, (int)wf.size(), depth, w, h, cn, src_row_bytes, alpha, border_mode, border_value, is_affine,
-                                      acc, acc_stride_floats, accumulate);
+                                      acc, acc_stride_floats, accumulate, 0, dw, dh);
     if (st) return st;
     // the host vector may die before the copy above ran if the caller does not synchronise
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -457,7 +457,7 @@ stk_status warp_fold(stk_ctx* ctx, std::vector<WarpFrame>& wf, int depth, int w,
 // the fold launch itself over entries [first_frame, first_frame + n_frames) of ctx->warpframes (device memory); asynchronous
 stk_status warp_fold_enqueue(stk_ctx* ctx, int n_frames, int depth, int w, int h, int cn, size_t src_row_bytes, double alpha,
                              int border_mode, const double* border_value, int is_affine, float* acc, size_t acc_stride_floats,
-                             int accumulate, int first_frame) {
+                             int accumulate, int first_frame, int dw, int dh) {
     WarpArgs a{};
     a.frames = ctx->warpframes.as<WarpFrame>() + first_frame;
     a.n_frames = n_frames;
@@ -466,7 +466,7 @@ stk_status warp_fold_enqueue(stk_ctx* ctx, int n_frames, int depth, int w, int h
     a.alpha = (float)alpha;
     a.border_mode = border_mode;
     for (int c = 0; c < 4; c++) a.bv[c] = border_value ? (float)border_value[c] : 0.f;
-    a.acc = acc; a.dw = w; a.dh = h; a.acc_stride = acc_stride_floats;
+    a.acc = acc; a.dw = dw > 0 ? dw : w; a.dh = dh > 0 ? dh : h; a.acc_stride = acc_stride_floats;
     a.accumulate = accumulate; a.is_affine = is_affine; a.subpixel_bits = ctx->opt_subpixel_bits; a.tune = ctx->opt_warp_tune;
     HIP_TRY(launch_warp_accumulate(a, depth, ctx->stream));
     ctx->timing.warp_launches += 1;

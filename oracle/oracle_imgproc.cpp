@@ -230,6 +230,18 @@ int orc_warp_frame(const void* src, int depth, int w, int h, int cn, size_t stri
                     alpha, subpixel_bits, w, h, dst, accumulate);
 }
 
+// the same with a destination of its own size: warp_perspective(src, M, dsize = (dw, dh)) — keypoint_match warps every frame
+// into the FIRST frame's size, whatever its own (lib.rs:290-299)
+int orc_warp_frame_sized(const void* src, int depth, int sw, int sh, int cn, size_t stride_bytes,
+                         const double* M, int is_affine, int border_mode, const double* border_value,
+                         double alpha, int subpixel_bits, float* dst, int dw, int dh, int accumulate) {
+    double Minv[9];
+    if (is_affine) invert_affine(M, Minv);
+    else invert3x3(M, Minv);
+    return orc_warp(src, depth, sw, sh, cn, stride_bytes, Minv, is_affine, border_mode, border_value,
+                    alpha, subpixel_bits, dw, dh, dst, accumulate);
+}
+
 // G1: acc = acc + img (cv::add, f32).
 int orc_add(float* acc, const float* img, size_t n) {
     for (size_t i = 0; i < n; i++) acc[i] = acc[i] + img[i];

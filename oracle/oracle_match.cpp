@@ -16,6 +16,9 @@ int orc_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void
 int orc_warp_frame(const void* src, int depth, int w, int h, int cn, size_t stride_bytes, const double* M,
                    int is_affine, int border_mode, const double* border_value, double alpha, int subpixel_bits,
                    float* dst, int accumulate);
+int orc_warp_frame_sized(const void* src, int depth, int sw, int sh, int cn, size_t stride_bytes, const double* M,
+                         int is_affine, int border_mode, const double* border_value, double alpha, int subpixel_bits,
+                         float* dst, int dw, int dh, int accumulate);
 int orc_scale(const float* in, size_t n, double divisor, float* out);
 int orc_scaled_size(int w, int h, float scale_down, int* nw, int* nh);
 int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
@@ -420,10 +423,32 @@ int orc_find_homography(const float* src_pts, const float* dst_pts, int n, int m
 // Returns 0 ok, 1 NotEnoughFiles, 2 all frames dropped (InvalidParams, lib.rs:324), 4 backend error.
 // scale_down > 0 selects keypoint_match_scale_down (lib.rs:355-601): ORB on INTER_AREA-shrunk greys, homography
 // estimated there, then adjust_homography_for_scale_f64 (utils.rs:218-248) before the full-size warp.
+// ws / hs (n entries each, or null): per-frame sizes of a stack whose frames differ in size — every frame is read and
+// described at its own size (lib.rs:200-204) and warped into the first frame's (lib.rs:290-299); (w, h) is then frame 0's.
+static int keypoint_match_impl(const void* const* frames, int n, int w, int h, const int* ws, const int* hs, int method, double thr,
+                               float keep_ratio, float match_ratio, int border_mode, const double* border_value, float scale_down,
+                               float* out, int* dropped_out, double* H_out, int* status_out, int n_threads);
+
 int orc_keypoint_match(const void* const* frames, int n, int w, int h, int method, double thr, float keep_ratio,
                        float match_ratio, int border_mode, const double* border_value, float scale_down, float* out,
                        int* dropped_out, double* H_out, int* status_out, int n_threads) {
+    return keypoint_match_impl(frames, n, w, h, nullptr, nullptr, method, thr, keep_ratio, match_ratio, border_mode, border_value,
+                               scale_down, out, dropped_out, H_out, status_out, n_threads);
+}
+
+int orc_keypoint_match_sized(const void* const* frames, int n, const int* ws, const int* hs, int method, double thr, float keep_ratio,
+                             float match_ratio, int border_mode, const double* border_value, float* out,
+                             int* dropped_out, double* H_out, int* status_out, int n_threads) {
     if (n <= 0) return 1;
+    return keypoint_match_impl(frames, n, ws[0], hs[0], ws, hs, method, thr, keep_ratio, match_ratio, border_mode, border_value,
+                               0.f, out, dropped_out, H_out, status_out, n_threads);
+}
+
+static int keypoint_match_impl(const void* const* frames, int n, int w, int h, const int* ws, const int* hs, int method, double thr,
+                               float keep_ratio, float match_ratio, int border_mode, const double* border_value, float scale_down,
+                               float* out, int* dropped_out, double* H_out, int* status_out, int n_threads) {
+    if (n <= 0) return 1;
+    if (ws && scale_down > 0) return 3;
     const size_t npx = (size_t)w * h, nel = npx * 3;
     int ew = w, eh = h;
     if (scale_down > 0) {
@@ -455,14 +480,15 @@ int orc_keypoint_match(const void* const* frames, int n, int w, int h, int metho
 #endif
         double Hm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         int status = 0;
+        const int wi = ws ? ws[i] : w, hi = hs ? hs[i] : h;       // this frame's own size
         if (i > 0) {
-            std::vector<uint8_t> g(npx);
-            orc_grey(frames[i], 8, w, h, 0, g.data());
+            std::vector<uint8_t> g((size_t)wi * hi);
+            orc_grey(frames[i], 8, wi, hi, 0, g.data());
             if (scale_down > 0) { std::vector<uint8_t> sm((size_t)ew * eh); orc_resize_area_u8(g.data(), w, h, sm.data(), ew, eh); g.swap(sm); }
             std::vector<float> kp((size_t)MAXKP * 7);
             std::vector<uint8_t> de((size_t)MAXKP * 32);
             int nk = 0;
-            orc_orb_detect_and_compute(g.data(), ew, eh, MAXKP, kp.data(), de.data(), &nk);
+            orc_orb_detect_and_compute(g.data(), ws ? wi : ew, hs ? hi : eh, MAXKP, kp.data(), de.data(), &nk);
             // query = frame-0 descriptors, train = frame-i descriptors (lib.rs:208-219)
             std::vector<int> knn((size_t)std::max(n0, 1) * 4);
             orc_bf_knn2_hamming(de0.data(), n0, de.data(), nk, knn.data());
@@ -509,7 +535,7 @@ int orc_keypoint_match(const void* const* frames, int n, int w, int h, int metho
         const bool fresh = acc.empty();
         if (fresh) acc.assign(nel, 0.f);
         if (i == 0) orc_warp_frame(frames[0], 8, w, h, 3, 0, I3, 1, BORDER_CONSTANT, nullptr, 1.0 / 255.0, 0, acc.data(), fresh ? 0 : 1);
-        else orc_warp_frame(frames[i], 8, w, h, 3, 0, Hm, 0, border_mode, border_value, 1.0 / 255.0, 0, acc.data(), fresh ? 0 : 1);
+        else orc_warp_frame_sized(frames[i], 8, wi, hi, 3, 0, Hm, 0, border_mode, border_value, 1.0 / 255.0, 0, acc.data(), w, h, fresh ? 0 : 1);
     }
     if (err) return err;
     if (dropped_out) *dropped_out = dropped;

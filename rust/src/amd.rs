@@ -112,13 +112,16 @@ fn new_output(w: i32, h: i32) -> Result<(Mat, stk_image_f32), StackerError> {
     Ok((out, img))
 }
 
-/// The frames of a stack decoded by OpenCV (the fallback for file types the engine does not read): every Mat must have the
-/// first one's size and type, because `stk_frames` carries ONE geometry for the whole stack (a smaller later frame would
-/// be read out of bounds otherwise). The reference's keypoint path accepts frames of differing size (lib.rs:166, 200-204);
-/// until the engine's per-frame geometry entry point is bound here such a stack is refused instead of mis-read.
+/// The frames of a stack decoded by OpenCV (the fallback for file types the engine does not read). `stk_frames` carries ONE
+/// geometry for the whole stack, so `frames()` insists on it (the ECC path: the reference fails on frames of differing
+/// size anyway, cv::add at lib.rs:809); the keypoint path hands every Mat's own geometry to `stk_keypoint_match_mixed`,
+/// which treats such a stack as the reference does (ORB per frame size, every frame warped into the first frame's size:
+/// lib.rs:166, 200-204, 290-299). Type (channels, depth) must match in both.
 struct DecodedStack {
     mats: Vec<Mat>,
     ptrs: Vec<*const c_void>,
+    geometry: Vec<stk_frame_geometry>,
+    uniform: bool,
 }
 
 impl DecodedStack {
@@ -128,6 +131,7 @@ impl DecodedStack {
             .map(|p| utils::imread(p, imgcodecs::IMREAD_UNCHANGED))
             .collect::<Result<_, _>>()?;
         let first = mats.first().ok_or(StackerError::NotEnoughFiles)?;
+        let mut uniform = true;
         for (m, p) in mats.iter().zip(files) {
             if m.empty() {
                 return Err(StackerError::OpenCvError(opencv::Error::new(
@@ -135,21 +139,47 @@ impl DecodedStack {
                     format!("{}: not an image", p.display()),
                 )));
             }
-            if m.size()? != first.size()? || m.typ() != first.typ() {
-                return Err(StackerError::InvalidParams(format!(
-                    "{}: size or type differs from the first frame's",
-                    p.display()
+            if m.typ() != first.typ() {
+                return Err(StackerError::OpenCvError(opencv::Error::new(
+                    core::StsError,
+                    format!("{}: type differs from the first frame's", p.display()),
                 )));
             }
             if !m.is_continuous() {
                 return Err(StackerError::ProcessingError("imread returned a non-continuous Mat".into()));
             }
+            uniform &= m.size()? == first.size()?;
         }
         let ptrs = mats.iter().map(|m| m.data() as *const c_void).collect();
-        Ok(Self { mats, ptrs })
+        let geometry = mats
+            .iter()
+            .map(|m| stk_frame_geometry { width: m.cols(), height: m.rows(), row_stride_bytes: 0 })
+            .collect();
+        Ok(Self { mats, ptrs, geometry, uniform })
     }
 
+    fn depth(&self) -> Result<i32, StackerError> {
+        Ok(match self.mats[0].depth() {
+            core::CV_8U => STK_DEPTH_U8,
+            core::CV_16U => STK_DEPTH_U16,
+            core::CV_32F => STK_DEPTH_F32,
+            _ => return Err(StackerError::NotImplemented),
+        })
+    }
+
+    /// One geometry for the whole stack, or the error the reference ends in on such a stack (cv::add, lib.rs:809).
     fn frames(&self) -> Result<stk_frames, StackerError> {
+        if !self.uniform {
+            return Err(StackerError::OpenCvError(opencv::Error::new(
+                core::StsUnmatchedSizes,
+                "the frames differ in size".to_string(),
+            )));
+        }
+        self.frames_of_first()
+    }
+
+    /// `stk_frames` with the FIRST frame's geometry (what `stk_keypoint_match_mixed` reads channels / depth / location from).
+    fn frames_of_first(&self) -> Result<stk_frames, StackerError> {
         let m = &self.mats[0];
         Ok(stk_frames {
             data: self.ptrs.as_ptr(),
@@ -157,12 +187,7 @@ impl DecodedStack {
             width: m.cols(),
             height: m.rows(),
             channels: m.channels(),
-            depth: match m.depth() {
-                core::CV_8U => STK_DEPTH_U8,
-                core::CV_16U => STK_DEPTH_U16,
-                core::CV_32F => STK_DEPTH_F32,
-                _ => return Err(StackerError::NotImplemented),
-            },
+            depth: self.depth()?,
             location: STK_HOST,
             row_stride_bytes: 0,
         })
@@ -238,9 +263,17 @@ pub(crate) fn keypoint_match(
         Err(st) => return Err(to_err(ctx, st)),
     }
     let stack = DecodedStack::read(files)?;
-    let frames = stack.frames()?;
+    let frames = stack.frames_of_first()?;
     let (out, mut img) = new_output(frames.width, frames.height)?;
-    let st = unsafe { stk_keypoint_match(ctx, &frames, &p, sdw, &mut img, &mut dropped, std::ptr::null_mut()) };
+    let st = if stack.uniform {
+        unsafe { stk_keypoint_match(ctx, &frames, &p, sdw, &mut img, &mut dropped, std::ptr::null_mut()) }
+    } else if scale_down_width.is_some() {
+        return Err(StackerError::NotImplemented); // keypoint_match_scale_down on frames of differing size
+    } else {
+        unsafe {
+            stk_keypoint_match_mixed(ctx, &frames, stack.geometry.as_ptr(), &p, &mut img, &mut dropped, std::ptr::null_mut())
+        }
+    };
     if st == STK_OK { Ok((dropped, out)) } else { Err(to_err(ctx, st)) }
 }
 
