@@ -80,7 +80,10 @@ typedef struct {
     const void* const* data;        /* n pointers */
     int32_t n;
     int32_t width, height;
-    int32_t channels;               /* 3 (BGR); 1 is accepted by stage-level calls only */
+    int32_t channels;               /* 3 (BGR) or 4 (BGRA, what imread(IMREAD_UNCHANGED) makes of a PNG with alpha: grey comes
+                                       from B, G, R — cvtColor ignores the fourth channel, utils.rs:136-142 — and the stacked image
+                                       has four channels too, the fourth being the aligned, averaged alpha / 255, exactly what the
+                                       reference's convertTo / warp / add do to it); 1 is accepted by stage-level calls only */
     int32_t depth;                  /* STK_DEPTH_* */
     int32_t location;               /* STK_HOST | STK_DEVICE */
     size_t  row_stride_bytes;       /* 0 = tightly packed */
@@ -92,7 +95,7 @@ typedef struct {
     size_t  row_stride_bytes;       /* 0 = tightly packed */
 } stk_frame_geometry;
 
-/* Caller-allocated f32 image (the returned CV_32FC3 Mat, lib.rs:98,656). */
+/* Caller-allocated f32 image (the returned CV_32FC3 Mat, lib.rs:98,656; CV_32FC4 — channels = 4 — for BGRA stacks). */
 typedef struct {
     float*  data;
     int32_t width, height, channels;
@@ -175,7 +178,8 @@ void        stk_host_free(void* p);
  *   "ecc_slots"          frames iterated concurrently by one ECC launch (0 = auto: the whole stack in one round up to 128 frames,
  *                        beyond that at least three equal rounds of at most 96; rounds of at most 64 for frames up to 1080p;
  *                        1..256); changes no result
- *   "ecc_blocks"         workgroups per ECC launch, all frames in flight together (0 = auto: 288 per frame); a non-zero
+ *   "ecc_blocks"         workgroups per ECC launch, all frames in flight together (0 = auto: per frame (column strips x rows) /
+ *                        (4 x 112), at most 288 — a function of the frame size only: 288 at 4K, 72 at 1080p); a non-zero
  *                        value changes the f32 summation partition, i.e. results at round-off level (within the stated
  *                        ECC tolerance)
  *   "ecc_variant"        ECC pixel-pass kernel: 3 production (default), 0 the direct cross-check version
@@ -242,7 +246,10 @@ stk_status stk_ecc_match(stk_ctx* ctx, const stk_frames* frames,
  * lib.rs:306-316 / 807-814) in `sum` (device memory) and the number of frames
  * added; the caller reduces sums/counts across ranks (RCCL) and then calls
  * stk_finalize_mean once on the root. add_reference != 0 adds frame 0 itself
- * (lib.rs:194-196, 752-754) — exactly one rank does that. */
+ * (lib.rs:194-196, 752-754) — exactly one rank does that.
+ * On any status other than STK_OK the contents of `sum` are UNDEFINED (the fold is enqueued on the device behind the
+ * alignment and may already have overwritten it when a frame's failure reaches the host; the reference's `?` yields no
+ * image at all): do not reduce or reuse it. */
 stk_status stk_ecc_match_shard(stk_ctx* ctx, const stk_frames* frames,
                                const stk_ecc_params* params, float scale_down_width,
                                int32_t add_reference, stk_image_f32* sum,
@@ -276,12 +283,13 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
 
 /* ---- file front-end ---------------------------------------------------------
  * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit), grey / YCbCr
- * JPEG (libjpeg-turbo's libjpeg.so.8, OpenCV's decoder family at its default settings), 8- and 16-bit grey / RGB PNG
- * (libpng16.so.16) and stripped 8/16-bit grey / RGB TIFF (libtiff.so.5 / .6), the libraries loaded at run time: BGR or
- * grey rows, tightly packed, into `data` (capacity_bytes); data == NULL only reports the geometry. ctx may be NULL.
- * PNG with an alpha channel decodes to 4 or 2 channels under IMREAD_UNCHANGED and the reference's cvtColor(BGR2GRAY)
- * rejects that: STK_BACKEND_ERROR, like a file that is unreadable or not an image (the reference's empty Mat + cvtColor).
- * Other flavours (CMYK JPEG, tiled TIFF, palette PNG, BMP / WebP / EXR ...) -> STK_NOT_IMPLEMENTED. */
+ * JPEG (libjpeg-turbo's libjpeg.so.8, OpenCV's decoder family at its default settings), PNG (libpng16.so.16: 8- and 16-bit
+ * grey / RGB, palette -> BGR, 1/2/4-bit grey -> 8 bit; anything with alpha — RGBA, grey + alpha, a tRNS chunk — comes out as
+ * FOUR channels B G R A, as OpenCV's decoder delivers it under IMREAD_UNCHANGED) and stripped 8/16-bit grey / RGB TIFF
+ * (libtiff.so.5 / .6), the libraries loaded at run time: BGR(A) or grey rows, tightly packed, into `data` (capacity_bytes);
+ * data == NULL only reports the geometry. ctx may be NULL. A file that is unreadable or not an image: STK_BACKEND_ERROR (the
+ * reference's empty Mat + cvtColor). Flavours no decoder here takes (CMYK JPEG, tiled TIFF, BMP / WebP / EXR ...):
+ * STK_NOT_IMPLEMENTED — the caller decodes those itself and uses the frame-based entry points. */
 stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width,
                       int32_t* height, int32_t* channels, int32_t* depth);
 /* keypoint_match / ecc_match in the reference's own call shape: a list of file paths, first = reference frame

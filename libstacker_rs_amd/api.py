@@ -300,16 +300,17 @@ class Stacker:
         """Frames of differing size (host arrays, HxWx3 u8): ORB at each frame's own size, every frame warped into the FIRST
         frame's size, as the reference does (lib.rs:166, 200-204, 290-299) — stk_keypoint_match_mixed."""
         arrs = [np.ascontiguousarray(f.cpu().numpy() if _is_torch(f) else f) for f in frames]
+        cn = arrs[0].shape[2] if arrs[0].ndim == 3 else 0
         for a in arrs:
-            if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
-                raise OpenCvError("ORB: 8-bit BGR frames expected")
+            if a.ndim != 3 or a.shape[2] not in (3, 4) or a.shape[2] != cn or a.dtype != np.uint8:
+                raise OpenCvError("ORB: 8-bit BGR / BGRA frames of one type expected")
         n = len(arrs)
         ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
         geo = (_ffi.FrameGeometry * n)(*[_ffi.FrameGeometry(a.shape[1], a.shape[0], 0) for a in arrs])
         h0, w0 = arrs[0].shape[:2]
-        fr = _ffi.Frames(C.cast(ptrs, C.POINTER(C.c_void_p)), n, w0, h0, 3, 8, HOST, 0)
-        out = np.empty((h0, w0, 3), np.float32)
-        img = _ffi.ImageF32(out.ctypes.data, w0, h0, 3, HOST, 0)
+        fr = _ffi.Frames(C.cast(ptrs, C.POINTER(C.c_void_p)), n, w0, h0, cn, 8, HOST, 0)
+        out = np.empty((h0, w0, cn), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w0, h0, cn, HOST, 0)
         stats = (_ffi.FrameStats * n)()
         dropped = C.c_int32(0)
         p = params._c()
@@ -443,16 +444,16 @@ class Stacker:
     def _file_geometry(self, files):
         w, h, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._check(self._lib.stk_imread(self._h, os.fsencode(files[0]), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)))
-        return w.value, h.value
+        return w.value, h.value, (4 if c.value == 4 else 3)       # (an RGBA file gives a CV_32FC4 stack, like the reference)
 
     def keypoint_match_files(self, files, params: KeyPointMatchParameters, scale_down_width: Optional[float] = None):
         """keypoint_match(files, params, scale_down_width) -> (dropped, HxWx3 f32)   lib.rs:129-137"""
         files = list(files)
         if not files:
             raise NotEnoughFiles("Not enough files")
-        w, h = self._file_geometry(files)
-        out = np.empty((h, w, 3), np.float32)
-        img = _ffi.ImageF32(out.ctypes.data, w, h, 3, HOST, 0)
+        w, h, cn = self._file_geometry(files)
+        out = np.empty((h, w, cn), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w, h, cn, HOST, 0)
         keep, arr = self._paths(files)
         dropped = C.c_int32(0)
         p = params._c()
@@ -465,9 +466,9 @@ class Stacker:
         files = list(files)
         if not files:
             raise NotEnoughFiles("Not enough files")
-        w, h = self._file_geometry(files)
-        out = np.empty((h, w, 3), np.float32)
-        img = _ffi.ImageF32(out.ctypes.data, w, h, 3, HOST, 0)
+        w, h, cn = self._file_geometry(files)
+        out = np.empty((h, w, cn), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w, h, cn, HOST, 0)
         keep, arr = self._paths(files)
         p = params._c()
         self._check(self._lib.stk_ecc_match_files(self._h, arr, len(files), C.byref(p), float(scale_down_width or 0.0),
@@ -479,9 +480,9 @@ class Stacker:
         files = list(files)
         if not files:
             raise NotEnoughFiles("Not enough files")
-        w, h = self._file_geometry(files)
-        out = np.empty((h, w, 3), np.float32)
-        img = _ffi.ImageF32(out.ctypes.data, w, h, 3, HOST, 0)
+        w, h, cn = self._file_geometry(files)
+        out = np.empty((h, w, cn), np.float32)
+        img = _ffi.ImageF32(out.ctypes.data, w, h, cn, HOST, 0)
         keep, arr = self._paths(files)
         kp, ep = kp_params._c(), ecc_params._c()
         self._check(self._lib.stk_hybrid_match_files(self._h, arr, len(files), C.byref(kp), C.byref(ep), C.byref(img), None))

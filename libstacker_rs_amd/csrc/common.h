@@ -177,7 +177,7 @@ struct WarpArgs {
 
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------
 hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void* out, hipStream_t s,
-                       int n_frames = 1, size_t src_frame_bytes = 0, size_t out_frame_elems = 0);
+                       int n_frames = 1, size_t src_frame_bytes = 0, size_t out_frame_elems = 0, int cn = 3 /* 3 BGR, 4 BGRA */);
 hipError_t launch_convert_f32(const void* src, int depth, size_t n, float alpha, float* out, hipStream_t s);
 // BGR (cn==3) or grey (cn==1) image -> GaussianBlur(float(grey), ksize) f32 plane with row stride out_stride
 hipError_t launch_grey16_to_8(const uint16_t* src, size_t n, uint8_t* dst, hipStream_t s);

@@ -20,6 +20,7 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
     if (st) return st;
     if (!kp_params || !ecc_params) return fail(ctx, STK_INVALID_PARAMS, "null params");
     if (frames->depth != 8 && frames->depth != 16) return fail(ctx, STK_INVALID_PARAMS, "hybrid match takes 8- or 16-bit BGR frames");
+    if (frames->channels != 3) return fail(ctx, STK_INVALID_PARAMS, "hybrid match takes 3-channel frames");
     if (ecc_params->motion_type != STK_MOTION_HOMOGRAPHY)
         return fail(ctx, STK_INVALID_PARAMS, "hybrid match seeds a homography: motion type must be Homography");
     const int n = frames->n;

@@ -115,6 +115,8 @@ struct PngApi {
     void (*set_expand_gray_1_2_4_to_8)(void*) = nullptr;
     void (*set_swap)(void*) = nullptr;
     void (*set_bgr)(void*) = nullptr;
+    void (*set_gray_to_rgb)(void*) = nullptr;
+    void (*set_tRNS_to_alpha)(void*) = nullptr;
     int (*set_interlace_handling)(void*) = nullptr;
     void (*read_update_info)(void*, void*) = nullptr;
     size_t (*get_rowbytes)(void*, void*) = nullptr;
@@ -134,11 +136,12 @@ const PngApi& png_api() {
         STK_PNG_SYM(read_info, "png_read_info"); STK_PNG_SYM(get_IHDR, "png_get_IHDR"); STK_PNG_SYM(get_valid, "png_get_valid");
         STK_PNG_SYM(set_palette_to_rgb, "png_set_palette_to_rgb"); STK_PNG_SYM(set_expand_gray_1_2_4_to_8, "png_set_expand_gray_1_2_4_to_8");
         STK_PNG_SYM(set_swap, "png_set_swap"); STK_PNG_SYM(set_bgr, "png_set_bgr"); STK_PNG_SYM(set_interlace_handling, "png_set_interlace_handling");
+        STK_PNG_SYM(set_gray_to_rgb, "png_set_gray_to_rgb"); STK_PNG_SYM(set_tRNS_to_alpha, "png_set_tRNS_to_alpha");
         STK_PNG_SYM(read_update_info, "png_read_update_info"); STK_PNG_SYM(get_rowbytes, "png_get_rowbytes"); STK_PNG_SYM(read_row, "png_read_row");
 #undef STK_PNG_SYM
         a.ok = a.get_libpng_ver && a.create_read_struct && a.create_info_struct && a.destroy_read_struct && a.set_longjmp_fn && a.longjmp_ &&
                a.init_io && a.read_info && a.get_IHDR && a.get_valid && a.set_palette_to_rgb && a.set_expand_gray_1_2_4_to_8 && a.set_swap &&
-               a.set_bgr && a.set_interlace_handling && a.read_update_info && a.get_rowbytes && a.read_row;
+               a.set_bgr && a.set_gray_to_rgb && a.set_tRNS_to_alpha && a.set_interlace_handling && a.read_update_info && a.get_rowbytes && a.read_row;
         return a;
     }();
     return api;
@@ -150,7 +153,7 @@ static void png_trap_error(void* png, const char*) { png_api().longjmp_(png, 1);
 // One pass over the file. pix == nullptr: geometry only (w, h, cn, depth out). Else the decoded rows go to pix, which holds
 // w * h * cn * depth / 8 bytes. libpng reports errors by longjmp into this frame: it owns no object with a destructor and
 // touches nothing but PODs, the FILE* and the caller's buffer (the reason for the two passes: the buffer exists beforehand).
-// 0 ok; 1 not decodable; 2 a flavour this build does not take (alpha: the reference would stack four channels).
+// 0 ok; 1 not decodable; 2 a flavour this build does not take.
 static int png_decode_raw(const PngApi& api, const char* path, int* w, int* h, int* cn, int* depth, unsigned char* pix) noexcept {
     FILE* volatile f = std::fopen(path, "rb");
     if (!f) return 1;
@@ -171,18 +174,22 @@ static int png_decode_raw(const PngApi& api, const char* path, int* w, int* h, i
     int bits = 0, color = 0, interlace = 0, comp = 0, filter = 0;
     api.get_IHDR(png, info, &iw, &ih, &bits, &color, &interlace, &comp, &filter);
     int rc = 0;
-    const bool has_alpha = (color & 4) != 0 || api.get_valid(png, info, 0x10u /* PNG_INFO_tRNS */) != 0;
+    const bool has_trns = api.get_valid(png, info, 0x10u /* PNG_INFO_tRNS */) != 0;
+    const bool has_alpha = (color & 4) != 0 || has_trns;
     if (iw == 0 || ih == 0 || iw > 65500 || ih > 65500) rc = 1;
-    else if (has_alpha) rc = 2;
     else {
         *w = (int)iw; *h = (int)ih;
-        *cn = (color & 2) ? 3 : 1;                           // PNG_COLOR_MASK_COLOR (palette images carry it too)
+        // IMREAD_UNCHANGED keeps an alpha plane: every PNG with alpha (RGBA, grey + alpha, a tRNS chunk) comes out of
+        // OpenCV's PngDecoder as FOUR channels, B G R A (grey replicated) [OCV-RECALL]; the reference then stacks all four
+        *cn = has_alpha ? 4 : (color & 2) ? 3 : 1;           // PNG_COLOR_MASK_COLOR (palette images carry it too)
         *depth = bits == 16 ? 16 : 8;
         if (pix) {
             if (color == 3) api.set_palette_to_rgb(png);     // PNG_COLOR_TYPE_PALETTE
-            if (color == 0 && bits < 8) api.set_expand_gray_1_2_4_to_8(png);
+            if ((color & 2) == 0 && bits < 8) api.set_expand_gray_1_2_4_to_8(png);
+            if (has_trns) api.set_tRNS_to_alpha(png);
+            if (has_alpha && (color & 2) == 0) api.set_gray_to_rgb(png);
             if (bits == 16) api.set_swap(png);               // big-endian file order -> native (x86-64)
-            if (*cn == 3) api.set_bgr(png);
+            if (*cn >= 3) api.set_bgr(png);
             const int passes = api.set_interlace_handling(png);
             api.read_update_info(png, info);
             const size_t row = (size_t)iw * *cn * (*depth / 8);
@@ -469,8 +476,8 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
         const int rc = png_load(path, p, file);
         if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }                      // already decoded
         if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
-        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': PNG with an alpha channel or tRNS chunk is not decoded in this "
-                                              "build, nor any PNG when libpng is missing (libpng16.so.16 " + (png_api().ok ? "loaded" : "not found") + ")");
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': a PNG flavour this build does not decode, or libpng is "
+                                              "missing (libpng16.so.16 " + (png_api().ok ? "loaded" : "not found") + ")");
     }
     if (has_ext(path, ".tif") || has_ext(path, ".tiff")) {
         const int rc = tiff_load(path, p, file);

@@ -28,13 +28,14 @@ __device__ __forceinline__ float grey_f32(float b, float g, float r) {
 }
 
 // blockIdx.z = frame of a batch: source frames `src_frame_stride` elements apart, outputs `out_frame_stride` apart
-template <typename T>
+// CN = 3 (BGR) or 4 (BGRA: cvtColor(BGR2GRAY) takes four channels and ignores the fourth, utils.rs:136-142)
+template <typename T, int CN>
 __global__ __launch_bounds__(256) void grey_kernel(const T* __restrict__ src, size_t stride, int w, int h,
                                                    T* __restrict__ out, size_t src_frame_stride, size_t out_frame_stride) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     src += blockIdx.z * src_frame_stride; out += blockIdx.z * out_frame_stride;
-    const T* p = src + (size_t)y * stride + (size_t)x * 3;
+    const T* p = src + (size_t)y * stride + (size_t)x * CN;
     T v;
     if constexpr (sizeof(T) == 1) v = grey_u8(p[0], p[1], p[2]);
     else if constexpr (sizeof(T) == 2) v = grey_u16(p[0], p[1], p[2]);
@@ -59,17 +60,19 @@ __global__ __launch_bounds__(256) void grey_u8x4_kernel(const uint8_t* __restric
 
 // n_frames > 1: frames `src_frame_bytes` apart in memory, grey images `out_frame_elems` elements apart
 hipError_t launch_grey(const void* bgr, int depth, int w, int h, size_t stride_bytes, void* out, hipStream_t s,
-                       int n_frames, size_t src_frame_bytes, size_t out_frame_elems) {
-    if (depth == 8 && w % 4 == 0 && stride_bytes % 4 == 0 && src_frame_bytes % 4 == 0 && out_frame_elems % 4 == 0 &&
+                       int n_frames, size_t src_frame_bytes, size_t out_frame_elems, int cn) {
+    if (cn != 3 && cn != 4) return hipErrorInvalidValue;
+    if (cn == 3 && depth == 8 && w % 4 == 0 && stride_bytes % 4 == 0 && src_frame_bytes % 4 == 0 && out_frame_elems % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(bgr) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
         dim3 g4((w / 4 + 255) / 256, h, n_frames);
         grey_u8x4_kernel<<<g4, 256, 0, s>>>((const uint8_t*)bgr, stride_bytes, w, h, (uint8_t*)out, src_frame_bytes, out_frame_elems);
         return hipGetLastError();
     }
     dim3 grid((w + 255) / 256, h, n_frames);
-    if (depth == 8) grey_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)bgr, stride_bytes, w, h, (uint8_t*)out, src_frame_bytes, out_frame_elems);
-    else if (depth == 16) grey_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)bgr, stride_bytes / 2, w, h, (uint16_t*)out, src_frame_bytes / 2, out_frame_elems);
-    else grey_kernel<float><<<grid, 256, 0, s>>>((const float*)bgr, stride_bytes / 4, w, h, (float*)out, src_frame_bytes / 4, out_frame_elems);
+#define STK_GREY(T, CN, div) grey_kernel<T, CN><<<grid, 256, 0, s>>>((const T*)bgr, stride_bytes / div, w, h, (T*)out, src_frame_bytes / div, out_frame_elems)
+    if (cn == 3) { if (depth == 8) STK_GREY(uint8_t, 3, 1); else if (depth == 16) STK_GREY(uint16_t, 3, 2); else STK_GREY(float, 3, 4); }
+    else { if (depth == 8) STK_GREY(uint8_t, 4, 1); else if (depth == 16) STK_GREY(uint16_t, 4, 2); else STK_GREY(float, 4, 4); }
+#undef STK_GREY
     return hipGetLastError();
 }
 
@@ -513,6 +516,9 @@ hipError_t launch_grey_blur(const void* src, int depth, int cn, int w, int h, si
     else if (depth == 16 && cn == 1) grey_blur_kernel<uint16_t, 1><<<grid, 256, lds_bytes, s>>>((const uint16_t*)src, stride_bytes / 2, w, h, taps, out, out_stride);
     else if (depth == 32 && cn == 3) grey_blur_kernel<float, 3><<<grid, 256, lds_bytes, s>>>((const float*)src, stride_bytes / 4, w, h, taps, out, out_stride);
     else if (depth == 32 && cn == 1) grey_blur_kernel<float, 1><<<grid, 256, lds_bytes, s>>>((const float*)src, stride_bytes / 4, w, h, taps, out, out_stride);
+    else if (depth == 8 && cn == 4) grey_blur_kernel<uint8_t, 4><<<grid, 256, lds_bytes, s>>>((const uint8_t*)src, stride_bytes, w, h, taps, out, out_stride);
+    else if (depth == 16 && cn == 4) grey_blur_kernel<uint16_t, 4><<<grid, 256, lds_bytes, s>>>((const uint16_t*)src, stride_bytes / 2, w, h, taps, out, out_stride);
+    else if (depth == 32 && cn == 4) grey_blur_kernel<float, 4><<<grid, 256, lds_bytes, s>>>((const float*)src, stride_bytes / 4, w, h, taps, out, out_stride);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

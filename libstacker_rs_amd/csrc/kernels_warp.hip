@@ -520,6 +520,9 @@ hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
     else if (depth == 16 && a.cn == 1) STK_WARP_CASE(uint16_t, 1);
     else if (depth == 32 && a.cn == 3) STK_WARP_CASE(float, 3);
     else if (depth == 32 && a.cn == 1) STK_WARP_CASE(float, 1);
+    else if (depth == 8 && a.cn == 4) STK_WARP_CASE(uint8_t, 4);        // BGRA: the alpha plane is warped and summed like a colour (the
+    else if (depth == 16 && a.cn == 4) STK_WARP_CASE(uint16_t, 4);      // reference converts, warps and adds whatever imread returned)
+    else if (depth == 32 && a.cn == 4) STK_WARP_CASE(float, 4);
     else return hipErrorInvalidValue;
 #undef STK_WARP_CASE
     return hipGetLastError();

@@ -507,6 +507,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     if (params->border_mode < 0 || params->border_mode > 4)
         return fail(ctx, params->border_mode == STK_BORDER_TRANSPARENT ? STK_NOT_IMPLEMENTED : STK_BACKEND_ERROR, "unsupported border mode");
     const int w = frames->width, h = frames->height, n = frames->n;
+    const int cn = frames->channels;                     // 3, or 4 (BGRA: grey from B, G, R — cvtColor ignores the fourth channel)
     if (w >= 65536 || h >= 32768) return fail(ctx, STK_INVALID_PARAMS, "image too large for ORB");
     // keypoint_match_scale_down (lib.rs:355-601): ORB and the homography on INTER_AREA-shrunk greys
     const bool scaled = scale_down_width > 0;
@@ -596,8 +597,8 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
         auto grey_level0 = [&](const void* frame, int slot) -> stk_status {
             uint8_t* l0 = ws->pyr.as<uint8_t>() + (size_t)slot * g.pyr.total;
             if (depth16) { HIP_TRY_C(c, launch_bgr16_to_grey8(frame, w, h, rb, l0, s)); return STK_OK; }   // grey16 -> (g + 128) / 257
-            if (!scaled) { HIP_TRY_C(c, launch_grey(frame, 8, w, h, rb, l0, s)); return STK_OK; }
-            HIP_TRY_C(c, launch_grey(frame, 8, w, h, rb, ws->gfull.p, s));
+            if (!scaled) { HIP_TRY_C(c, launch_grey(frame, 8, w, h, rb, l0, s, 1, 0, 0, cn)); return STK_OK; }
+            HIP_TRY_C(c, launch_grey(frame, 8, w, h, rb, ws->gfull.p, s, 1, 0, 0, cn));
             HIP_TRY_C(c, launch_resize_area_u8(ws->gfull.as<uint8_t>(), w, h, l0, ew, eh, s));
             return STK_OK;
         };
@@ -614,7 +615,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
             const ptrdiff_t fstep = nb > 1 ? (const uint8_t*)dev[b0 + 1] - (const uint8_t*)dev[b0] : 0;
             for (int k = 1; even && k + 1 < nb; k++) even = ((const uint8_t*)dev[b0 + k + 1] - (const uint8_t*)dev[b0 + k]) == fstep;
             if (even && fstep > 0 && depth16) HIP_TRY_C(c, launch_bgr16_to_grey8(dev[b0], w, h, rb, ws->pyr.as<uint8_t>(), s, nb, (size_t)fstep, g.pyr.total));
-            else if (even && fstep > 0) HIP_TRY_C(c, launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total));
+            else if (even && fstep > 0) HIP_TRY_C(c, launch_grey(dev[b0], 8, w, h, rb, ws->pyr.p, s, nb, (size_t)fstep, g.pyr.total, cn));
             else
                 for (int k = 0; k < nb; k++)
                     if ((st = grey_level0(dev[b0 + k], k))) return st;
@@ -811,8 +812,8 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
                                     int32_t* n_added, int32_t* n_dropped, stk_frame_stats* stats) {
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
-    const int w = frames->width, h = frames->height, n = frames->n;
-    if ((st = image_check(ctx, sum, w, h, 3))) return st;
+    const int w = frames->width, h = frames->height, n = frames->n, cn = frames->channels;
+    if ((st = image_check(ctx, sum, w, h, cn))) return st;
     if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
     timing_begin(ctx);
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -849,7 +850,7 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
             HIP_TRY(hipEventRecord(a, ctx->stream));
         }
         HIP_TRY(hipMemcpyAsync(ctx->warpframes.as<WarpFrame>() + first, wf.data() + first, sizeof(WarpFrame) * (size_t)cnt, hipMemcpyHostToDevice, ctx->stream));
-        const stk_status fs = warp_fold_enqueue(ctx, cnt, 8, w, h, 3, rb, 1.0 / 255.0, params->border_mode, params->border_value, 0, sum->data,
+        const stk_status fs = warp_fold_enqueue(ctx, cnt, 8, w, h, cn, rb, 1.0 / 255.0, params->border_mode, params->border_value, 0, sum->data,
                                                 image_stride_floats(sum), first > 0 ? 1 : 0, first);
         if (fs) return fs;
         if (timed) HIP_TRY(hipEventRecord(fold_ev.back().second, ctx->stream));
@@ -881,10 +882,10 @@ stk_status stk_keypoint_match(stk_ctx* ctx, const stk_frames* frames, const stk_
     if (ctx && ctx->multi) return multi_match(ctx, 1, frames, params, nullptr, scale_down_width, out, dropped, stats);
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
-    if ((st = image_check(ctx, out, frames->width, frames->height, 3))) return st;
+    if ((st = image_check(ctx, out, frames->width, frames->height, frames->channels))) return st;
     if (out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "output must be tightly packed");
     (void)hipSetDevice(ctx->device);
-    const size_t nel = (size_t)frames->width * frames->height * 3;
+    const size_t nel = (size_t)frames->width * frames->height * frames->channels;
     stk_image_f32 sum = *out;
     if (out->location != STK_DEVICE) {
         HIP_TRY(ctx->acc.reserve(nel * sizeof(float)));

@@ -44,17 +44,18 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
     }
     if (ctx->multi) return fail(ctx, STK_NOT_IMPLEMENTED, "frames of differing size on a multi-device context");
     if (!params) return fail(ctx, STK_INVALID_PARAMS, "null params");
-    if (frames->channels != 3) return fail(ctx, STK_BACKEND_ERROR, "cvtColor(BGR2GRAY): 3-channel frames expected");
+    if (frames->channels != 3 && frames->channels != 4) return fail(ctx, STK_BACKEND_ERROR, "cvtColor(BGR2GRAY): frames must have 3 or 4 channels (utils.rs:136)");
+    const int cn = frames->channels;
     if (frames->depth != 8) return fail(ctx, STK_BACKEND_ERROR, "ORB: only 8-bit images are supported");
     if (params->border_mode < 0 || params->border_mode > 4)
         return fail(ctx, params->border_mode == STK_BORDER_TRANSPARENT ? STK_NOT_IMPLEMENTED : STK_BACKEND_ERROR, "unsupported border mode");
     const int dw = geometry[0].width, dh = geometry[0].height;
     stk_status st;
-    if ((st = image_check(ctx, out, dw, dh, 3))) return st;
+    if ((st = image_check(ctx, out, dw, dh, cn))) return st;
     if (out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "output must be tightly packed");
     (void)hipSetDevice(ctx->device);
     timing_begin(ctx);
-    const size_t nel = (size_t)dw * dh * 3;
+    const size_t nel = (size_t)dw * dh * cn;
     float* sum = out->data;
     if (out->location != STK_DEVICE) {
         HIP_TRY(ctx->acc.reserve(nel * sizeof(float)));
@@ -65,8 +66,8 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
     // one frame on the device at a time (host frames are uploaded once, into the context's frame buffer)
     size_t max_bytes = 0, max_px = 0;
     for (int i = 0; i < n; i++) {
-        const size_t rb = geometry[i].row_stride_bytes ? geometry[i].row_stride_bytes : (size_t)geometry[i].width * 3;
-        if (rb < (size_t)geometry[i].width * 3) return fail(ctx, STK_INVALID_PARAMS, "frame " + std::to_string(i) + ": row stride below the row's bytes");
+        const size_t rb = geometry[i].row_stride_bytes ? geometry[i].row_stride_bytes : (size_t)geometry[i].width * cn;
+        if (rb < (size_t)geometry[i].width * cn) return fail(ctx, STK_INVALID_PARAMS, "frame " + std::to_string(i) + ": row stride below the row's bytes");
         max_bytes = std::max(max_bytes, rb * (size_t)geometry[i].height);
         max_px = std::max(max_px, (size_t)geometry[i].width * geometry[i].height);
     }
@@ -81,7 +82,7 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
     const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int i = 0; i < n; i++) {
         const int w = geometry[i].width, h = geometry[i].height;
-        const size_t rb = geometry[i].row_stride_bytes ? geometry[i].row_stride_bytes : (size_t)w * 3;
+        const size_t rb = geometry[i].row_stride_bytes ? geometry[i].row_stride_bytes : (size_t)w * cn;
         if (!frames->data[i]) return fail(ctx, STK_INVALID_PARAMS, "frame " + std::to_string(i) + ": null data");
         const void* dev = frames->data[i];
         if (host) {
@@ -90,7 +91,7 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
         }
         stk_frames one{};
         const void* one_ptr = dev;
-        one.data = &one_ptr; one.n = 1; one.width = w; one.height = h; one.channels = 3; one.depth = 8;
+        one.data = &one_ptr; one.n = 1; one.width = w; one.height = h; one.channels = cn; one.depth = 8;
         one.location = STK_DEVICE; one.row_stride_bytes = rb;
         if ((st = stk_grey(ctx, &one, grey))) return st;                                     // utils.rs:136-142
         float* kps = i == 0 ? kp0.data() : kp.data();
@@ -143,8 +144,8 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
         // warp_perspective(frame i, H, dsize = the first frame's) + add (lib.rs:290-316); frame 0 under the identity (lib.rs:194-196)
         std::vector<WarpFrame> wf(1);
         make_warp_frame(wf[0], dev, i == 0 ? I3 : H, 0);
-        if ((st = warp_fold(ctx, wf, 8, w, h, 3, rb, 1.0 / 255.0, i == 0 ? STK_BORDER_CONSTANT : params->border_mode,
-                            i == 0 ? nullptr : params->border_value, 0, sum, (size_t)dw * 3, added > 0 ? 1 : 0, dw, dh))) return st;
+        if ((st = warp_fold(ctx, wf, 8, w, h, cn, rb, 1.0 / 255.0, i == 0 ? STK_BORDER_CONSTANT : params->border_mode,
+                            i == 0 ? nullptr : params->border_value, 0, sum, (size_t)dw * cn, added > 0 ? 1 : 0, dw, dh))) return st;
         added++;
     }
     if (dropped_out) *dropped_out = dropped;

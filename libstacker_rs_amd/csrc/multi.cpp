@@ -105,10 +105,11 @@ stk_status multi_match(stk_ctx* ctx, int kind, const stk_frames* frames, const s
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
     const int w = frames->width, h = frames->height, n = frames->n;
-    if ((st = image_check(ctx, out, w, h, 3))) return st;
+    const int cn = frames->channels == 4 ? 4 : 3;
+    if ((st = image_check(ctx, out, w, h, cn))) return st;
     if (out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "output must be tightly packed");
     const int world = (int)ms->members.size();
-    const size_t nel = (size_t)w * h * 3;
+    const size_t nel = (size_t)w * h * cn;
     for (int r = 0; r < world; r++) {
         (void)hipSetDevice(ms->devices[r]);
         HIP_TRY(ms->sums[r].reserve(nel * sizeof(float)));
@@ -153,7 +154,7 @@ stk_status multi_match(stk_ctx* ctx, int kind, const stk_frames* frames, const s
                 }
             }
         }
-        stk_image_f32 sum{ms->sums[r].as<float>(), w, h, 3, STK_DEVICE, 0};
+        stk_image_f32 sum{ms->sums[r].as<float>(), w, h, cn, STK_DEVICE, 0};
         sub_stats[r].resize(sub.n);
         stk_frame_stats* sst = stats ? sub_stats[r].data() : nullptr;
         const int add_ref = r == 0;
@@ -219,7 +220,7 @@ stk_status multi_match(stk_ctx* ctx, int kind, const stk_frames* frames, const s
     if (dropped_out) *dropped_out = tot_dropped;
     if (tot_added <= 0)   // lib.rs:324
         return fail(ctx, STK_INVALID_PARAMS, "All images discarded: try modifying KeyPointMatchParameters::match_distance_threshold");
-    stk_image_f32 sum0{ms->sums[0].as<float>(), w, h, 3, STK_DEVICE, 0};
+    stk_image_f32 sum0{ms->sums[0].as<float>(), w, h, cn, STK_DEVICE, 0};
     // keypoint: img / (n - dropped) (lib.rs:342); ecc / hybrid: img / n (lib.rs:836-839)
     return stk_finalize_mean(ctx, &sum0, kind == MULTI_KEYPOINT ? (int64_t)n - tot_dropped : (int64_t)n, out);
 }

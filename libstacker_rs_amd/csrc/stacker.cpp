@@ -39,9 +39,10 @@ stk_status check_frames(stk_ctx* ctx, const stk_frames* f, bool need_bgr) {
     if (!f || f->n <= 0 || !f->data) return fail(ctx, STK_NOT_ENOUGH_FILES, "Not enough files");
     if (f->width <= 0 || f->height <= 0) return fail(ctx, STK_INVALID_PARAMS, "bad frame geometry");
     if (f->depth != 8 && f->depth != 16 && f->depth != 32) return fail(ctx, STK_INVALID_PARAMS, "depth must be 8, 16 or 32");
-    if (need_bgr && f->channels != 3)
-        return fail(ctx, STK_BACKEND_ERROR, "cvtColor(BGR2GRAY): frames must have 3 channels (utils.rs:136)");
-    if (f->channels != 1 && f->channels != 3) return fail(ctx, STK_INVALID_PARAMS, "channels must be 1 or 3");
+    // cvtColor(BGR2GRAY) takes 3 or 4 channels (utils.rs:136-142); IMREAD_UNCHANGED hands a PNG's alpha plane through (utils.rs:132)
+    if (need_bgr && f->channels != 3 && f->channels != 4)
+        return fail(ctx, STK_BACKEND_ERROR, "cvtColor(BGR2GRAY): frames must have 3 or 4 channels (utils.rs:136)");
+    if (f->channels != 1 && f->channels != 3 && f->channels != 4) return fail(ctx, STK_INVALID_PARAMS, "channels must be 1, 3 or 4");
     if ((size_t)f->width * f->height > (size_t)1 << 30) return fail(ctx, STK_INVALID_PARAMS, "frame too large");
     return STK_OK;
 }
@@ -514,7 +515,8 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         if (frames->depth != 8) return fail(ctx, STK_NOT_IMPLEMENTED, "ecc_match with scale_down_width: only 8-bit frames");
         if (!scaled_size(w, h, scale_down_width, ew, eh)) return fail(ctx, STK_INVALID_PARAMS, "scale_down_width gives an empty image");
     }
-    if ((st = image_check(ctx, sum, w, h, 3))) return st;
+    const int cn = frames->channels;                    // 3 (BGR) or 4 (BGRA: the output is CV_32FC4 like the reference's)
+    if ((st = image_check(ctx, sum, w, h, cn))) return st;
     if (sum->location != STK_DEVICE) return fail(ctx, STK_INVALID_PARAMS, "shard sum must be device memory");
     timing_begin(ctx);
 
@@ -546,8 +548,8 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     // one moving frame's template on stream `s`: grey (-> scale_image) -> blur
     auto prepare_template = [&](int i, hipStream_t s) -> stk_status {
         float* t = ctx->templates.as<float>() + pl.templ_plane_stride * (size_t)(i - 1);
-        if (!scaled) { HIP_TRY(launch_grey_blur(dev[i], frames->depth, 3, w, h, rb, params->gauss_filt_size, t, pl.templ_row_stride, s)); return STK_OK; }
-        HIP_TRY(launch_grey(dev[i], 8, w, h, rb, gfull, s));
+        if (!scaled) { HIP_TRY(launch_grey_blur(dev[i], frames->depth, cn, w, h, rb, params->gauss_filt_size, t, pl.templ_row_stride, s)); return STK_OK; }
+        HIP_TRY(launch_grey(dev[i], 8, w, h, rb, gfull, s, 1, 0, 0, cn));
         HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, s));
         HIP_TRY(launch_grey_blur(gsmall, 8, 1, ew, eh, (size_t)ew, params->gauss_filt_size, t, pl.templ_row_stride, s));
         return STK_OK;
@@ -559,7 +561,7 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         bool even = !scaled && count >= 2 && ctx->opt_prep_stream;
         const ptrdiff_t step = count >= 2 ? (const char*)dev[first + 1] - (const char*)dev[first] : 0;
         for (int k = 1; even && k + 1 < count; k++) even = ((const char*)dev[first + k + 1] - (const char*)dev[first + k]) == step;
-        if (even && step > 0) {
+        if (even && step > 0 && cn == 3) {                          // (the streaming kernel reads 3-channel pixels; BGRA goes frame by frame)
             const hipError_t e = launch_grey_blur_batch(nullptr, dev[first], (size_t)step, count, frames->depth, w, h, rb, params->gauss_filt_size,
                                                         ctx->templates.as<float>() + pl.templ_plane_stride * (size_t)(first - 1), pl.templ_row_stride,
                                                         pl.templ_plane_stride, s);
@@ -570,8 +572,8 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         return STK_OK;
     };
     auto prepare_reference = [&](hipStream_t s) -> stk_status {
-        if (!scaled) return ecc_prepare_reference(ctx, pl, dev[0], frames->depth, 3, rb, params->gauss_filt_size);
-        HIP_TRY(launch_grey(dev[0], 8, w, h, rb, gfull, s));
+        if (!scaled) return ecc_prepare_reference(ctx, pl, dev[0], frames->depth, cn, rb, params->gauss_filt_size);
+        HIP_TRY(launch_grey(dev[0], 8, w, h, rb, gfull, s, 1, 0, 0, cn));
         HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, s));
         return ecc_prepare_reference(ctx, pl, gsmall, 8, 1, (size_t)ew, params->gauss_filt_size);
     };
@@ -607,7 +609,7 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
             HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * (size_t)n_out));
             HIP_TRY(launch_warp_frames_from_ecc(ctx->results.as<EccFrameResult>(), ctx->frameptrs.as<const void*>(), n - 1, add_reference ? 1 : 0,
                                                 is_affine, w, h, rb, ctx->warpframes.as<WarpFrame>(), ctx->stream));
-            const stk_status fs = warp_fold_enqueue(ctx, n_out, frames->depth, w, h, 3, rb, alpha, STK_BORDER_CONSTANT, nullptr, is_affine,
+            const stk_status fs = warp_fold_enqueue(ctx, n_out, frames->depth, w, h, cn, rb, alpha, STK_BORDER_CONSTANT, nullptr, is_affine,
                                                     sum->data, image_stride_floats(sum), 0);
             if (fs) return fs;
         } else {
@@ -722,7 +724,7 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
         make_warp_frame(wf.back(), dev[i], M, is_affine);
     }
     if (wf.empty()) HIP_TRY(hipMemsetAsync(sum->data, 0, image_stride_floats(sum) * h * sizeof(float), ctx->stream));
-    if ((st = warp_fold(ctx, wf, frames->depth, w, h, 3, rb, alpha, STK_BORDER_CONSTANT, nullptr, is_affine,
+    if ((st = warp_fold(ctx, wf, frames->depth, w, h, cn, rb, alpha, STK_BORDER_CONSTANT, nullptr, is_affine,
                         sum->data, image_stride_floats(sum), 0))) return st;
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -769,10 +771,10 @@ stk_status stk_ecc_match(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_p
     if (ctx && ctx->multi) return multi_match(ctx, 0, frames, nullptr, params, scale_down_width, out, nullptr, stats);
     stk_status st = check_frames(ctx, frames, true);
     if (st) return st;
-    if ((st = image_check(ctx, out, frames->width, frames->height, 3))) return st;
+    if ((st = image_check(ctx, out, frames->width, frames->height, frames->channels))) return st;
     if (out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "output must be tightly packed");
     (void)hipSetDevice(ctx->device);
-    const size_t nel = (size_t)frames->width * frames->height * 3;
+    const size_t nel = (size_t)frames->width * frames->height * frames->channels;
     stk_image_f32 sum = *out;
     if (out->location != STK_DEVICE) {
         HIP_TRY(ctx->acc.reserve(nel * sizeof(float)));
@@ -798,7 +800,7 @@ stk_status stk_grey(stk_ctx* ctx, const stk_frames* f, void* out) {
     const size_t ob = (size_t)f->width * f->height * (f->depth / 8);
     void* d = out;
     if (f->location == STK_HOST) { HIP_TRY(ctx->scratch.reserve(ob)); d = ctx->scratch.p; }
-    HIP_TRY(launch_grey(dev[0], f->depth, f->width, f->height, frame_row_bytes(f), d, ctx->stream));
+    HIP_TRY(launch_grey(dev[0], f->depth, f->width, f->height, frame_row_bytes(f), d, ctx->stream, 1, 0, 0, f->channels));
     if (f->location == STK_HOST) HIP_TRY(hipMemcpyAsync(out, d, ob, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STK_OK;

@@ -178,7 +178,7 @@ def test_imread_pnm_without_a_gpu(tmp_path):
 
 def test_imread_png_through_runtime_libpng(tmp_path, write_png):
     """PNG via libpng's row API loaded at run time (no headers in the image): 8- and 16-bit grey / RGB, palette, low-bit
-    grey; alpha and a missing libpng -> NOT_IMPLEMENTED."""
+    grey, RGBA -> BGRA; a missing libpng -> NOT_IMPLEMENTED."""
     import ctypes.util
     lib = _ffi.load()
     rng = np.random.default_rng(1)
@@ -203,7 +203,19 @@ def test_imread_png_through_runtime_libpng(tmp_path, write_png):
     og = np.empty_like(grey)
     assert lib.stk_imread(None, os.fsencode(tmp_path / "g.png"), C.c_void_p(og.ctypes.data), og.nbytes, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
     assert c.value == 1 and np.array_equal(og, grey)
-    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), None, 0, None, None, None, None) == 7       # alpha: not taken
+    # alpha: IMREAD_UNCHANGED keeps it — four channels, B G R A (round 4; the reference then stacks all four, utils.rs:132-142)
+    rgba = rng.integers(0, 256, (4, 4, 4), dtype=np.uint8)
+    write_png(tmp_path / "a.png", rgba)                                        # (four-channel arrays go to disk as given: R G B A)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+    assert (w.value, h.value, c.value, d.value) == (4, 4, 4, 8)
+    oa = np.empty_like(rgba)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a.png"), C.c_void_p(oa.ctypes.data), oa.nbytes, None, None, None, None) == 0
+    assert np.array_equal(oa, rgba[..., [2, 1, 0, 3]])
+    rgba16 = rng.integers(0, 65536, (3, 5, 4), dtype=np.uint16)
+    write_png(tmp_path / "a16.png", rgba16)
+    oa16 = np.empty_like(rgba16)
+    assert lib.stk_imread(None, os.fsencode(tmp_path / "a16.png"), C.c_void_p(oa16.ctypes.data), oa16.nbytes, C.byref(w), C.byref(h), C.byref(c), C.byref(d)) == 0
+    assert (c.value, d.value) == (4, 16) and np.array_equal(oa16, rgba16[..., [2, 1, 0, 3]])
     # 16-bit PNG (utils.rs:110-117: imread(UNCHANGED) keeps the depth -> 16UC3 / 16UC1): how a 16-bit stack (BASELINE
     # configs[4]) arrives besides TIFF; samples byte-swapped to native order, never gamma-converted
     c16 = rng.integers(0, 65536, (9, 14, 3), dtype=np.uint16)
