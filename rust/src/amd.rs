@@ -93,19 +93,22 @@ fn ecc_params(p: &EccMatchParameters) -> stk_ecc_params {
 }
 
 /// Geometry of the stack = geometry of its first file (the output has the reference frame's size, lib.rs:166, 290-299).
-fn first_geometry(ctx: *mut stk_ctx, first: &CString) -> Result<(i32, i32), stk_status> {
+fn first_geometry(ctx: *mut stk_ctx, first: &CString) -> Result<(i32, i32, i32), stk_status> {
     let (mut w, mut h, mut cn, mut depth) = (0i32, 0i32, 0i32, 0i32);
     let st = unsafe { stk_imread(ctx, first.as_ptr(), std::ptr::null_mut(), 0, &mut w, &mut h, &mut cn, &mut depth) };
-    if st == STK_OK { Ok((w, h)) } else { Err(st) }
+    if st == STK_OK { Ok((w, h, cn)) } else { Err(st) }
 }
 
-fn new_output(w: i32, h: i32) -> Result<(Mat, stk_image_f32), StackerError> {
-    let mut out = unsafe { Mat::new_rows_cols(h, w, core::CV_32FC3)? };
+/// The result Mat: CV_32FC3, or CV_32FC4 for a stack of BGRA frames (the reference's `&acc + &warped` keeps whatever
+/// channel count imread(IMREAD_UNCHANGED) delivered, utils.rs:132).
+fn new_output(w: i32, h: i32, cn: i32) -> Result<(Mat, stk_image_f32), StackerError> {
+    let cn = if cn == 4 { 4 } else { 3 };
+    let mut out = unsafe { Mat::new_rows_cols(h, w, if cn == 4 { core::CV_32FC4 } else { core::CV_32FC3 })? };
     let img = stk_image_f32 {
         data: out.data_mut() as *mut f32,
         width: w,
         height: h,
-        channels: 3,
+        channels: cn,
         location: STK_HOST,
         row_stride_bytes: 0,
     };
@@ -208,9 +211,9 @@ pub(crate) fn ecc_match(
     let p = ecc_params(&params);
     let sdw = scale_down_width.unwrap_or(0.0);
     match first_geometry(ctx, &paths[0]) {
-        Ok((w, h)) => {
+        Ok((w, h, cn)) => {
             let raw: Vec<*const std::os::raw::c_char> = paths.iter().map(|c| c.as_ptr()).collect();
-            let (out, mut img) = new_output(w, h)?;
+            let (out, mut img) = new_output(w, h, cn)?;
             let st = unsafe {
                 stk_ecc_match_files(ctx, raw.as_ptr(), raw.len() as i32, &p, sdw, &mut img, std::ptr::null_mut())
             };
@@ -225,7 +228,7 @@ pub(crate) fn ecc_match(
     }
     let stack = DecodedStack::read(files)?;
     let frames = stack.frames()?;
-    let (out, mut img) = new_output(frames.width, frames.height)?;
+    let (out, mut img) = new_output(frames.width, frames.height, frames.channels)?;
     let st = unsafe { stk_ecc_match(ctx, &frames, &p, sdw, &mut img, std::ptr::null_mut()) };
     if st == STK_OK { Ok(out) } else { Err(to_err(ctx, st)) }
 }
@@ -247,9 +250,9 @@ pub(crate) fn keypoint_match(
     // Frames whose homography cannot be estimated are skipped and COUNTED (the documented contract, lib.rs:98); every
     // frame dropped -> InvalidParams, as lib.rs:324. The tuple is (dropped, image / (n - dropped)), lib.rs:339-345.
     match first_geometry(ctx, &paths[0]) {
-        Ok((w, h)) => {
+        Ok((w, h, cn)) => {
             let raw: Vec<*const std::os::raw::c_char> = paths.iter().map(|c| c.as_ptr()).collect();
-            let (out, mut img) = new_output(w, h)?;
+            let (out, mut img) = new_output(w, h, cn)?;
             let st = unsafe {
                 stk_keypoint_match_files(ctx, raw.as_ptr(), raw.len() as i32, &p, sdw, &mut img, &mut dropped, std::ptr::null_mut())
             };
@@ -264,7 +267,7 @@ pub(crate) fn keypoint_match(
     }
     let stack = DecodedStack::read(files)?;
     let frames = stack.frames_of_first()?;
-    let (out, mut img) = new_output(frames.width, frames.height)?;
+    let (out, mut img) = new_output(frames.width, frames.height, frames.channels)?;
     let st = if stack.uniform {
         unsafe { stk_keypoint_match(ctx, &frames, &p, sdw, &mut img, &mut dropped, std::ptr::null_mut()) }
     } else if scale_down_width.is_some() {
