@@ -18,7 +18,11 @@ timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_IN
 echo "sq done"
 timeout -k 10 400 rocprofv3 --pmc TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum --kernel-trace --output-format csv -d $out/pmc_ta -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_ta.log 2>&1 || echo "ta pass failed"
 echo "ta done"
-cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $out > $out/summary.json && head -c 1500 $out/summary.json
+# round 4: the scalar unit, LDS and branch instruction counts (the ECC pass was co-limited by its scalar bookkeeping) and
+# the clock the chip holds under the kernel (GRBM_GUI_ACTIVE / 8 XCDs / duration)
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_sq2 -- python3 $GRAFT_REPO_ROOT/bench.py $args --profile-launches 0 > $out/pmc_sq2.log 2>&1 || echo "sq2 pass failed"
+echo "sq2 done"
+cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $out $PIN > $out/summary.json && head -c 1500 $out/summary.json
 # keep what is judged (per-kernel stats + summary), drop the raw per-dispatch traces (tens of MB; gpurun_out is capped)
 cp $out/trace/*/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
-rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/pmc_ta
+rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/pmc_ta $out/pmc_sq2
