@@ -13,7 +13,7 @@ sets) — concatenated (bench.py ignores a stale one).
 Round 4 adds, per kernel: SQ_INSTS_SALU / LDS / BRANCH / SMEM, the clock held (GRBM_GUI_ACTIVE / 8 / mean duration) and, for the
 ECC pass, `_issue_slots_per_px`: the STATIC cost of the ring loop's row in issue slots (tools/isa_loops.py on the kernel's ISA,
 built here with the Makefile's flags; a plain f32 / simple integer instruction = 1 slot = 2.15 SIMD cycles, packed / conversion /
-three-operand / DPP ... = 2, v_rcp_f32 = 4: tools/valu_rates.hip) divided by the 64 pixels of a row, plus the strip's set-up and
+three-operand / DPP ... = 2, v_rcp_f32 = 4: tools/valu_rates.hip) per row = per pixel of a lane, plus the strip's set-up and
 fold spread over its 112 rows — what roofline.valu of the bench line is computed from."""
 import collections
 import csv
@@ -98,7 +98,7 @@ if ek:
                                             'lds': best[3], 'vmem_static': best[4]}
             # + strip set-up (corner tests, ring fill) and the 66-sum lane fold, once per strip of ~112 rows: ~700 slots (isa_loops: the
             # depth-1 loop minus its inner loops), i.e. ~6 per row
-            out[ek]['_issue_slots_per_px'] = (best[1] / rows + 6.0) / 64.0
+            out[ek]['_issue_slots_per_px'] = best[1] / rows + 6.0      # per pixel = per lane and row, like SQ_INSTS_VALU x 64 / pixels
     except Exception as e:                                # no hipcc on this machine: the dynamic counters stand alone
         out[ek]['_issue_slots_note'] = 'static cost not computed: %s' % e
     if 'SQ_INSTS_VALU_per_dispatch' in out[ek] and 'SQ_WAVES_per_dispatch' in out[ek]:
