@@ -77,6 +77,9 @@ struct stk_ctx {
     const void* ref_zeroed_ptr = nullptr;   // the frame-0 planes' zero border exists for this buffer and geometry (ecc_prepare_reference)
     int ref_zeroed_w = 0, ref_zeroed_h = 0;
     std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
+    // page-locked host block the path-based entry points decode a stack into (imread.cpp: match_files); grow-only, like the
+    // device workspaces: locking 6.4 GB of pages for a 256-frame 4K stack costs more than decoding into them
+    unsigned char* files_block = nullptr; size_t files_block_cap = 0; bool files_block_pinned = false;
     // workspace
     DevBuf frames, ref, blur_tmp, templates, slots, queue, results, partials, warpframes, acc, scratch, init_warps, frameptrs;
     stk::KeypointWorkspace* kp = nullptr;

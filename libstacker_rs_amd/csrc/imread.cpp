@@ -81,13 +81,36 @@ bool has_ext(const char* path, const char* ext) {
     return true;
 }
 
+// R G B -> B G R of `px` 8-bit pixels. The byte loop below runs at ~1 GB/s per thread, which made the decoder pool the
+// slowest stage of the path-based entry points on uncompressed files (round 4: 256 x 4K from tmpfs, 16 threads, 8-10 GB/s
+// against the 55 GB/s of the PCIe link behind it); with SSSE3 five pixels go through one byte shuffle per 16-byte load
+// (the 16th byte is written too and overwritten by the next store; the last 16 bytes take the byte loop).
+#if defined(__x86_64__)
+__attribute__((target("ssse3"))) static size_t swap_rb_ssse3(const unsigned char* src, unsigned char* dst, size_t px) {
+    typedef char v16 __attribute__((vector_size(16)));
+    typedef char v16u __attribute__((vector_size(16), aligned(1)));
+    const v16 mask = {2, 1, 0, 5, 4, 3, 8, 7, 6, 11, 10, 9, 14, 13, 12, 15};
+    size_t i = 0;
+    for (; (i + 5) * 3 + 1 <= px * 3 && (i + 5) * 3 + 16 <= px * 3; i += 5)
+        *(v16u*)(dst + 3 * i) = __builtin_ia32_pshufb128(*(const v16u*)(src + 3 * i), mask);
+    return i;
+}
+#endif
+void swap_rb_u8(const unsigned char* src, unsigned char* dst, size_t px) {
+    size_t i = 0;
+#if defined(__x86_64__)
+    if (px >= 16 && __builtin_cpu_supports("ssse3")) i = swap_rb_ssse3(src, dst, px);
+#endif
+    for (; i < px; i++) { dst[3 * i] = src[3 * i + 2]; dst[3 * i + 1] = src[3 * i + 1]; dst[3 * i + 2] = src[3 * i]; }
+}
+
 // decode into `dst` (w*h*cn samples of depth/8 bytes): RGB -> BGR, 16-bit big-endian -> native
 void pnm_decode(const unsigned char* raster, const Pnm& p, void* dst) {
     const size_t px = (size_t)p.w * p.h;
     if (p.depth == 8) {
         unsigned char* o = (unsigned char*)dst;
         if (p.cn == 1) std::memcpy(o, raster, px);
-        else for (size_t i = 0; i < px; i++) { o[3 * i] = raster[3 * i + 2]; o[3 * i + 1] = raster[3 * i + 1]; o[3 * i + 2] = raster[3 * i]; }
+        else swap_rb_u8(raster, o, px);
     } else {
         unsigned short* o = (unsigned short*)dst;
         auto be = [&](size_t s) { return (unsigned short)((raster[2 * s] << 8) | raster[2 * s + 1]); };
@@ -276,7 +299,7 @@ int tiff_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
         if (api.read_scanline(t, line.data(), y, 0) < 0) { api.close(t); return 1; }
         unsigned char* o = pix.data() + row * y;
         if (!rgb) std::memcpy(o, line.data(), row);
-        else if (bps == 8) for (uint32_t x = 0; x < w; x++) { o[3 * x] = line[3 * x + 2]; o[3 * x + 1] = line[3 * x + 1]; o[3 * x + 2] = line[3 * x]; }
+        else if (bps == 8) swap_rb_u8(line.data(), o, w);
         else {
             const uint16_t* s16 = reinterpret_cast<const uint16_t*>(line.data());   // libtiff returns native byte order
             uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
@@ -524,13 +547,17 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
     stk_status st = load_image(ctx, paths[0], file0, first);
     if (st) return st;
     const size_t fbytes = (size_t)first.w * first.h * first.cn * (first.depth / 8);
-    struct Pinned {                       // page-locked when the runtime grants it, plain memory otherwise
-        unsigned char* p = nullptr; bool pinned = false;
-        ~Pinned() { if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); } }
-    } block;
-    if (hipHostMalloc((void**)&block.p, fbytes * (size_t)n, hipHostMallocDefault) == hipSuccess) block.pinned = true;
-    else { (void)hipGetLastError(); block.p = (unsigned char*)std::malloc(fbytes * (size_t)n); }
-    if (!block.p) return fail(ctx, STK_PROCESSING_ERROR, "out of host memory for the decoded stack");
+    // page-locked when the runtime grants it, plain memory otherwise; kept by the context and re-used by the next call
+    // (round 4: allocating and locking the block per call was a third of a 256-frame 4K call)
+    if (ctx->files_block_cap < fbytes * (size_t)n) {
+        if (ctx->files_block) { if (ctx->files_block_pinned) (void)hipHostFree(ctx->files_block); else std::free(ctx->files_block); }
+        ctx->files_block = nullptr; ctx->files_block_cap = 0;
+        if (hipHostMalloc((void**)&ctx->files_block, fbytes * (size_t)n, hipHostMallocDefault) == hipSuccess) ctx->files_block_pinned = true;
+        else { (void)hipGetLastError(); ctx->files_block = (unsigned char*)std::malloc(fbytes * (size_t)n); ctx->files_block_pinned = false; }
+        if (!ctx->files_block) return fail(ctx, STK_PROCESSING_ERROR, "out of host memory for the decoded stack");
+        ctx->files_block_cap = fbytes * (size_t)n;
+    }
+    struct { unsigned char* p; } block{ctx->files_block};
     auto place = [&](int i, std::vector<unsigned char>& file, const Pnm& p) {
         unsigned char* dst = block.p + fbytes * (size_t)i;
         if (p.data_ofs == (size_t)-1) std::memcpy(dst, file.data(), fbytes);             // decoded by a codec library

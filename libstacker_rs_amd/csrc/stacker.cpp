@@ -101,6 +101,7 @@ void stk_destroy(stk_ctx* ctx) {
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->prof_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->host_done) (void)hipHostFree(ctx->host_done);
+    if (ctx->files_block) { if (ctx->files_block_pinned) (void)hipHostFree(ctx->files_block); else std::free(ctx->files_block); }
     for (auto& e : ctx->upload_events) if (e) (void)hipEventDestroy(e);
     if (ctx->gate_ev) (void)hipEventDestroy(ctx->gate_ev);
     if (ctx->gate_ev2) (void)hipEventDestroy(ctx->gate_ev2);
