@@ -250,6 +250,8 @@ struct TiffApi {
     int (*read_scanline)(void*, void*, uint32_t, uint16_t) = nullptr;
     long (*scanline_size)(void*) = nullptr;
     int (*is_tiled)(void*) = nullptr;
+    long (*read_tile)(void*, void*, uint32_t, uint32_t, uint32_t, uint16_t) = nullptr;   // optional: tiled files
+    long (*tile_size)(void*) = nullptr;
     void* (*set_error_handler)(void*) = nullptr;
     void* (*set_warning_handler)(void*) = nullptr;
     bool ok = false;
@@ -267,6 +269,8 @@ const TiffApi& tiff_api() {
         a.read_scanline = reinterpret_cast<int (*)(void*, void*, uint32_t, uint16_t)>(dlsym(h, "TIFFReadScanline"));
         a.scanline_size = reinterpret_cast<long (*)(void*)>(dlsym(h, "TIFFScanlineSize"));
         a.is_tiled = reinterpret_cast<int (*)(void*)>(dlsym(h, "TIFFIsTiled"));
+        a.read_tile = reinterpret_cast<long (*)(void*, void*, uint32_t, uint32_t, uint32_t, uint16_t)>(dlsym(h, "TIFFReadTile"));
+        a.tile_size = reinterpret_cast<long (*)(void*)>(dlsym(h, "TIFFTileSize"));
         a.set_error_handler = reinterpret_cast<void* (*)(void*)>(dlsym(h, "TIFFSetErrorHandler"));
         a.set_warning_handler = reinterpret_cast<void* (*)(void*)>(dlsym(h, "TIFFSetWarningHandler"));
         a.ok = a.open && a.close && a.get_field && a.read_scanline && a.scanline_size && a.is_tiled;
@@ -276,7 +280,26 @@ const TiffApi& tiff_api() {
     return api;
 }
 
-// 8- or 16-bit, grey (MINISBLACK) or RGB, contiguous, stripped TIFF (any compression libtiff handles) -> grey / BGR
+// swap channels 0 and 2 of `px` pixels of CN channels of T (R G B [A] -> B G R [A])
+template <typename T, int CN>
+static void swap_02(const T* src, T* dst, size_t px) {
+    for (size_t i = 0; i < px; i++) {
+        const T a = src[CN * i], c = src[CN * i + 2];
+        dst[CN * i] = c; dst[CN * i + 1] = src[CN * i + 1]; dst[CN * i + 2] = a;
+        if (CN == 4) dst[CN * i + 3] = src[CN * i + 3];
+    }
+}
+// one decoded row (RGB / RGBA / grey samples in native byte order) -> B G R [A] / grey
+static void tiff_row_out(const unsigned char* line, unsigned char* o, uint32_t w, int cn, int bps) {
+    if (cn == 1) std::memcpy(o, line, (size_t)w * (bps / 8));
+    else if (cn == 3 && bps == 8) swap_rb_u8(line, o, w);
+    else if (cn == 3) swap_02<uint16_t, 3>(reinterpret_cast<const uint16_t*>(line), reinterpret_cast<uint16_t*>(o), w);
+    else if (bps == 8) swap_02<unsigned char, 4>(line, o, w);
+    else swap_02<uint16_t, 4>(reinterpret_cast<const uint16_t*>(line), reinterpret_cast<uint16_t*>(o), w);
+}
+
+// 8- or 16-bit, grey (MINISBLACK), RGB or RGBA (IMREAD_UNCHANGED keeps the fourth sample: B G R A), contiguous; stripped or
+// — round 4 — tiled (any compression libtiff handles) -> grey / BGR / BGRA
 // 0 decoded; 1 not decodable; 2 a flavour this build does not take
 int tiff_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
     const TiffApi& api = tiff_api();
@@ -288,28 +311,92 @@ int tiff_load(const char* path, Pnm& p, std::vector<unsigned char>& pix) {
     api.get_field(t, 256, &w); api.get_field(t, 257, &h);                  // IMAGEWIDTH, IMAGELENGTH
     api.get_field(t, 258, &bps); api.get_field(t, 277, &spp);              // BITSPERSAMPLE, SAMPLESPERPIXEL
     api.get_field(t, 262, &photo); api.get_field(t, 284, &planar);         // PHOTOMETRIC, PLANARCONFIG
-    const bool grey = spp == 1 && photo == 1, rgb = spp == 3 && photo == 2;
-    if (w == 0 || h == 0 || (bps != 8 && bps != 16) || (!grey && !rgb) || planar != 1 || api.is_tiled(t)) { api.close(t); return 2; }
-    p.w = (int)w; p.h = (int)h; p.cn = rgb ? 3 : 1; p.depth = bps; p.data_ofs = 0;
-    const size_t row = (size_t)w * p.cn * (bps / 8);
-    if ((size_t)api.scanline_size(t) < row) { api.close(t); return 1; }
-    pix.resize(row * h);
-    std::vector<unsigned char> line((size_t)api.scanline_size(t));
-    for (uint32_t y = 0; y < h; y++) {
-        if (api.read_scanline(t, line.data(), y, 0) < 0) { api.close(t); return 1; }
-        unsigned char* o = pix.data() + row * y;
-        if (!rgb) std::memcpy(o, line.data(), row);
-        else if (bps == 8) swap_rb_u8(line.data(), o, w);
-        else {
-            const uint16_t* s16 = reinterpret_cast<const uint16_t*>(line.data());   // libtiff returns native byte order
-            uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
-            for (uint32_t x = 0; x < w; x++) { o16[3 * x] = s16[3 * x + 2]; o16[3 * x + 1] = s16[3 * x + 1]; o16[3 * x + 2] = s16[3 * x]; }
+    const bool grey = spp == 1 && photo == 1, rgb = (spp == 3 || spp == 4) && photo == 2;
+    const bool tiled = api.is_tiled(t) != 0;
+    if (w == 0 || h == 0 || (bps != 8 && bps != 16) || (!grey && !rgb) || planar != 1 || (tiled && !(api.read_tile && api.tile_size))) { api.close(t); return 2; }
+    p.w = (int)w; p.h = (int)h; p.cn = rgb ? spp : 1; p.depth = bps; p.data_ofs = 0;
+    const size_t esz = (size_t)p.cn * (bps / 8), row = (size_t)w * esz;
+    if (!tiled) {
+        if ((size_t)api.scanline_size(t) < row) { api.close(t); return 1; }
+        pix.resize(row * h);
+        std::vector<unsigned char> line((size_t)api.scanline_size(t));
+        for (uint32_t y = 0; y < h; y++) {
+            if (api.read_scanline(t, line.data(), y, 0) < 0) { api.close(t); return 1; }
+            tiff_row_out(line.data(), pix.data() + row * y, w, p.cn, bps);
+        }
+    } else {
+        uint32_t tw = 0, th = 0;
+        api.get_field(t, 322, &tw); api.get_field(t, 323, &th);            // TILEWIDTH, TILELENGTH
+        const long tsz = api.tile_size(t);
+        if (tw == 0 || th == 0 || tsz <= 0 || (size_t)tsz < (size_t)tw * th * esz) { api.close(t); return 1; }
+        pix.resize(row * h);
+        std::vector<unsigned char> tile((size_t)tsz), band(row);
+        for (uint32_t y0 = 0; y0 < h; y0 += th) {
+            const uint32_t rows = std::min(th, h - y0);
+            // a band of tiles: decode each tile once, hand its rows over one image row at a time
+            std::vector<std::vector<unsigned char>> tiles;
+            for (uint32_t x0 = 0; x0 < w; x0 += tw) {
+                if (api.read_tile(t, tile.data(), x0, y0, 0, 0) < 0) { api.close(t); return 1; }
+                tiles.push_back(tile);
+            }
+            for (uint32_t y = 0; y < rows; y++) {
+                for (uint32_t x0 = 0, k = 0; x0 < w; x0 += tw, k++)
+                    std::memcpy(band.data() + (size_t)x0 * esz, tiles[k].data() + (size_t)y * tw * esz, (size_t)std::min(tw, w - x0) * esz);
+                tiff_row_out(band.data(), pix.data() + row * (y0 + y), w, p.cn, bps);
+            }
         }
     }
     api.close(t);
     return 0;
 }
 
+
+// ---- BMP (no library): uncompressed 24-bit -> BGR (the file's own order), 32-bit -> B G R A (IMREAD_UNCHANGED keeps the
+// fourth byte), 8-bit palette -> BGR, or one grey channel when every palette entry is grey [OCV-RECALL: BmpDecoder's
+// IsColorPalette]; bottom-up or top-down rows, rows padded to 4 bytes. 1 / 4 / 16-bit and RLE files: not taken.
+// 0 decoded; 1 not decodable; 2 a flavour this build does not take
+int bmp_load(const std::vector<unsigned char>& f, Pnm& p, std::vector<unsigned char>& pix) {
+    auto u16 = [&](size_t o) { return (uint32_t)f[o] | ((uint32_t)f[o + 1] << 8); };
+    auto u32 = [&](size_t o) { return u16(o) | (u16(o + 2) << 16); };
+    if (f.size() < 54 || f[0] != 'B' || f[1] != 'M') return 1;
+    const uint32_t data_ofs = u32(10), hsz = u32(14);
+    if (hsz < 40 || 14 + (size_t)hsz > f.size()) return hsz == 12 ? 2 : 1;          // (OS/2 core headers: not taken)
+    const int32_t w = (int32_t)u32(18), hraw = (int32_t)u32(22);
+    const uint32_t planes = u16(26), bpp = u16(28), comp = u32(30);
+    uint32_t ncol = u32(46);
+    const bool top_down = hraw < 0;
+    const int64_t h = top_down ? -(int64_t)hraw : hraw;
+    if (w <= 0 || h <= 0 || w > 65500 || h > 65500 || planes != 1) return 1;
+    if (!(bpp == 8 || bpp == 24 || bpp == 32) || !(comp == 0 || (comp == 3 && bpp == 32))) return 2;   // BI_RGB; BI_BITFIELDS only as 32-bit
+    if (comp == 3) {                       // the usual masks only: B G R (A) in memory order
+        const size_t mo = 14 + 40;
+        if (hsz < 52 && f.size() < mo + 12) return 1;
+        if (u32(mo) != 0x00ff0000u || u32(mo + 4) != 0x0000ff00u || u32(mo + 8) != 0x000000ffu) return 2;
+    }
+    const size_t src_row = (((size_t)w * bpp + 31) / 32) * 4;
+    if ((size_t)data_ofs + src_row * (size_t)h > f.size()) return 1;
+    const unsigned char* pal = nullptr;
+    bool grey_pal = false;
+    if (bpp == 8) {
+        if (ncol == 0 || ncol > 256) ncol = 256;
+        const size_t po = 14 + (size_t)hsz;
+        if (po + 4 * (size_t)ncol > f.size()) return 1;
+        pal = f.data() + po;                                  // B G R 0 per entry
+        grey_pal = true;
+        for (uint32_t i = 0; i < ncol; i++) grey_pal = grey_pal && pal[4 * i] == pal[4 * i + 1] && pal[4 * i] == pal[4 * i + 2];
+    }
+    const int cn = bpp == 32 ? 4 : (bpp == 24 || !grey_pal) ? 3 : 1;
+    pix.resize((size_t)w * h * cn);
+    for (int64_t y = 0; y < h; y++) {
+        const unsigned char* s = f.data() + data_ofs + src_row * (size_t)(top_down ? y : h - 1 - y);
+        unsigned char* o = pix.data() + (size_t)w * cn * (size_t)y;
+        if (bpp != 8) std::memcpy(o, s, (size_t)w * cn);
+        else if (grey_pal) for (int32_t x = 0; x < w; x++) o[x] = s[x] < ncol ? pal[4 * s[x]] : 0;
+        else for (int32_t x = 0; x < w; x++) { const unsigned char* e = pal + 4 * (s[x] < ncol ? s[x] : 0); o[3 * x] = e[0]; o[3 * x + 1] = e[1]; o[3 * x + 2] = e[2]; }
+    }
+    p.w = w; p.h = (int)h; p.cn = cn; p.depth = 8; p.data_ofs = 0;
+    return 0;
+}
 
 // ---- JPEG through libjpeg-turbo's classic API (libjpeg.so.8), resolved at run time --------------------------------------
 // The reference's own data set is JPEG (README.md:18, examples/main.rs:35) and OpenCV decodes it with this very library
@@ -502,11 +589,19 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
         return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': a PNG flavour this build does not decode, or libpng is "
                                               "missing (libpng16.so.16 " + (png_api().ok ? "loaded" : "not found") + ")");
     }
+    if (has_ext(path, ".bmp") || has_ext(path, ".dib")) {
+        std::vector<unsigned char> raw;
+        if (!read_file(path, raw)) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot read '") + path + "' (empty Mat -> cvtColor fails)");
+        const int rc = bmp_load(raw, p, file);
+        if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }
+        if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only uncompressed 8-bit palette, 24- and 32-bit BMP is decoded in this build");
+    }
     if (has_ext(path, ".tif") || has_ext(path, ".tiff")) {
         const int rc = tiff_load(path, p, file);
         if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }
         if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
-        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only stripped 8/16-bit grey or RGB TIFF is decoded in this "
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only contiguous 8/16-bit grey, RGB or RGBA TIFF is decoded in this "
                                               "build (libtiff " + (tiff_api().ok ? "loaded" : "not found") + ")");
     }
     if (has_ext(path, ".jpg") || has_ext(path, ".jpeg") || has_ext(path, ".jpe")) {

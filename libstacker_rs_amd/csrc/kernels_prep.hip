@@ -187,18 +187,18 @@ hipError_t launch_convert_f32(const void* src, int depth, size_t n, float alpha,
 }
 
 // ---- fused grey + Gaussian blur ---------------------------------------------------------------
-struct GaussTaps { float k[16]; int r; };   // k[i] = weight at distance i from the centre
+struct GaussTaps { float k[32]; int r; };   // k[i] = weight at distance i from the centre (kernel sizes up to 63: the tiled kernel's LDS tile)
 
 static bool gaussian_taps(int ksize, GaussTaps& t) {
-    if (ksize <= 0 || ksize % 2 == 0 || ksize > 31) return false;
+    if (ksize <= 0 || ksize % 2 == 0 || ksize > 63) return false;
     t.r = ksize / 2;
     static const float tab[4][4] = {{1.f, 0, 0, 0}, {0.5f, 0.25f, 0, 0}, {0.375f, 0.25f, 0.0625f, 0},
                                     {0.28125f, 0.21875f, 0.109375f, 0.03125f}};
-    for (int i = 0; i < 16; i++) t.k[i] = 0;
+    for (int i = 0; i < 32; i++) t.k[i] = 0;
     if (ksize <= 7) { for (int i = 0; i <= t.r; i++) t.k[i] = tab[t.r][i]; return true; }
     // cv::getGaussianKernel(n, sigma<=0): sigma = 0.3*((n-1)*0.5-1)+0.8, normalised exp(-x^2/2s^2), double -> f32
     const double sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8, sc = -0.5 / (sigma * sigma);
-    double sum = 0, v[32];
+    double sum = 0, v[64];
     for (int i = 0; i < ksize; i++) { double x = i - (ksize - 1) * 0.5; v[i] = std::exp(sc * x * x); sum += v[i]; }
     for (int i = 0; i <= t.r; i++) t.k[i] = (float)(v[t.r + i] * (1.0 / sum));
     return true;

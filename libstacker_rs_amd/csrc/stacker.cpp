@@ -197,7 +197,7 @@ static stk_status ecc_validate(stk_ctx* ctx, const stk_ecc_params* p, EccCriteri
     if (p->has_epsilon && p->epsilon < 0) return fail(ctx, STK_BACKEND_ERROR, "findTransformECC: epsilon < 0");
     if (p->gauss_filt_size <= 0 || p->gauss_filt_size % 2 == 0)
         return fail(ctx, STK_BACKEND_ERROR, "GaussianBlur: kernel size must be odd and positive");
-    if (p->gauss_filt_size > 31) return fail(ctx, STK_NOT_IMPLEMENTED, "gauss_filt_size > 31 is not supported");
+    if (p->gauss_filt_size > 63) return fail(ctx, STK_NOT_IMPLEMENTED, "gauss_filt_size > 63 is not supported");
     crit.n_iter = p->has_max_count ? p->max_count : 200;
     crit.eps = p->has_epsilon ? p->epsilon : -1;
     return STK_OK;
@@ -831,7 +831,7 @@ stk_status stk_gaussian_blur_f32(stk_ctx* ctx, const void* grey, int32_t depth, 
     if (!grey || !out || width <= 0 || height <= 0) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
     if (depth != 8 && depth != 32) return fail(ctx, STK_INVALID_PARAMS, "blur input must be u8 or f32");
     if (ksize <= 0 || ksize % 2 == 0) return fail(ctx, STK_BACKEND_ERROR, "GaussianBlur: kernel size must be odd and positive");
-    if (ksize > 31) return fail(ctx, STK_NOT_IMPLEMENTED, "ksize > 31 is not supported");
+    if (ksize > 63) return fail(ctx, STK_NOT_IMPLEMENTED, "ksize > 63 is not supported");
     (void)hipSetDevice(ctx->device);
     const size_t ib = (size_t)width * height * (depth / 8), ob = (size_t)width * height * 4;
     const void* src = grey; float* dst = out;
@@ -852,7 +852,7 @@ stk_status stk_grey_blur_f32(stk_ctx* ctx, const stk_frames* f, int32_t ksize, f
     if (!out) return fail(ctx, STK_INVALID_PARAMS, "null output");
     // (16-bit frames: only the hybrid extension runs ECC on them, on float(grey16); the stage is exposed for its tests)
     if (ksize <= 0 || ksize % 2 == 0) return fail(ctx, STK_BACKEND_ERROR, "GaussianBlur: kernel size must be odd and positive");
-    if (ksize > 31) return fail(ctx, STK_NOT_IMPLEMENTED, "ksize > 31 is not supported");
+    if (ksize > 63) return fail(ctx, STK_NOT_IMPLEMENTED, "ksize > 63 is not supported");
     (void)hipSetDevice(ctx->device);
     std::vector<const void*> dev;
     if ((st = resolve_frames(ctx, f, dev))) return st;

@@ -173,6 +173,86 @@ def _write_tiff(path, img):
         f.write(b"II" + struct.pack("<HI", 42, ifd_ofs) + ifd + struct.pack("<HHHH", bps, bps, bps, 0) + data)
 
 
+def _write_tiff_tiled(path, img, tile=(16, 16)):
+    """Tiled baseline TIFF (little-endian, uncompressed): 8/16-bit grey (HxW), RGB (HxWx3 given as BGR) or RGBA (HxWx4 given as BGRA)."""
+    import struct
+    a = np.asarray(img)
+    if a.ndim == 3:
+        a = a[..., [2, 1, 0] + ([3] if a.shape[2] == 4 else [])]
+    h, w = a.shape[:2]
+    spp = 1 if a.ndim == 2 else a.shape[2]
+    bps = a.dtype.itemsize * 8
+    tw, th = tile
+    tiles = []
+    for y0 in range(0, h, th):
+        for x0 in range(0, w, tw):
+            t = np.zeros((th, tw) + a.shape[2:], a.dtype)
+            blk = a[y0:y0 + th, x0:x0 + tw]
+            t[:blk.shape[0], :blk.shape[1]] = blk
+            tiles.append(t.astype("<u%d" % a.dtype.itemsize).tobytes())
+    nt = len(tiles)
+    tags = []
+    def tag(t, typ, count, value):
+        tags.append(struct.pack("<HHII", t, typ, count, value))
+    n_tags = 12 + (1 if spp == 4 else 0)
+    ifd_ofs = 8
+    extra_ofs = ifd_ofs + 2 + 12 * n_tags + 4
+    bps_ofs = extra_ofs
+    offs_ofs = bps_ofs + 8
+    cnts_ofs = offs_ofs + 4 * nt
+    data_ofs = cnts_ofs + 4 * nt
+    tag(256, 4, 1, w); tag(257, 4, 1, h)
+    tag(258, 3, spp, bps_ofs if spp > 2 else bps)
+    tag(259, 3, 1, 1); tag(262, 3, 1, 2 if spp >= 3 else 1)
+    tag(277, 3, 1, spp); tag(284, 3, 1, 1)
+    tag(322, 4, 1, tw); tag(323, 4, 1, th)
+    tag(324, 4, nt, offs_ofs if nt > 1 else data_ofs)
+    tag(325, 4, nt, cnts_ofs if nt > 1 else len(tiles[0]))
+    if spp == 4:
+        tag(338, 3, 1, 2)                                  # EXTRASAMPLES: unassociated alpha
+    tag(339, 3, 1, 1)                                      # SAMPLEFORMAT uint
+    assert len(tags) == n_tags
+    offs, o = [], data_ofs
+    for t in tiles:
+        offs.append(o); o += len(t)
+    with open(path, "wb") as f:
+        f.write(b"II" + struct.pack("<HI", 42, ifd_ofs) + struct.pack("<H", n_tags) + b"".join(tags) + struct.pack("<I", 0))
+        f.write(struct.pack("<HHHH", bps, bps, bps, bps))
+        f.write(struct.pack("<%dI" % nt, *offs) + struct.pack("<%dI" % nt, *[len(t) for t in tiles]))
+        f.write(b"".join(tiles))
+
+
+def _write_bmp(path, img, palette=None, top_down=False):
+    """Uncompressed BMP: HxWx3 (BGR, 24 bit), HxWx4 (BGRA, 32 bit) or HxW indices with an Nx3 BGR palette (8 bit)."""
+    import struct
+    a = np.asarray(img, np.uint8)
+    h, w = a.shape[:2]
+    bpp = 8 if a.ndim == 2 else a.shape[2] * 8
+    row = ((w * bpp + 31) // 32) * 4
+    rows = []
+    for y in (range(h) if top_down else range(h - 1, -1, -1)):
+        r = np.ascontiguousarray(a[y]).tobytes()
+        rows.append(r + b"\0" * (row - len(r)))
+    pal = b""
+    if bpp == 8:
+        pal = b"".join(bytes([int(c[0]), int(c[1]), int(c[2]), 0]) for c in np.asarray(palette, np.uint8))
+    ofs = 14 + 40 + len(pal)
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", ofs + row * h, 0, 0, ofs))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, bpp, 0, row * h, 2835, 2835, len(pal) // 4, 0))
+        f.write(pal + b"".join(rows))
+
+
+@pytest.fixture(scope="session")
+def write_tiff_tiled():
+    return _write_tiff_tiled
+
+
+@pytest.fixture(scope="session")
+def write_bmp():
+    return _write_bmp
+
+
 @pytest.fixture(scope="session")
 def write_tiff():
     """Writer of small test TIFFs (no Pillow in the main interpreter)."""

@@ -373,3 +373,60 @@ def test_rust_ffi_is_generated_from_the_header():
                          ("stk_image_f32", _ffi.ImageF32)):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % cname, committed, re.S).group(1)
         assert re.findall(r"pub (\w+):", body) == [f[0] for f in ctype._fields_], cname
+
+
+def _imread(lib, path):
+    w, h, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    st = lib.stk_imread(None, os.fsencode(path), None, 0, C.byref(w), C.byref(h), C.byref(c), C.byref(d))
+    if st:
+        return st, None
+    out = np.empty((h.value, w.value, c.value), np.uint8 if d.value == 8 else np.uint16)
+    st = lib.stk_imread(None, os.fsencode(path), C.c_void_p(out.ctypes.data), out.nbytes, None, None, None, None)
+    return st, (out[..., 0] if c.value == 1 else out)
+
+
+def test_imread_tiled_and_rgba_tiff(tmp_path, write_tiff_tiled):
+    """Round 4: tiled TIFF (TIFFReadTile; tiles overhanging the right and bottom edges) and RGBA TIFF (four channels, B G R A)."""
+    try:
+        C.CDLL("libtiff.so.5")
+    except OSError:
+        try:
+            C.CDLL("libtiff.so.6")
+        except OSError:
+            pytest.skip("libtiff is not installed here")
+    lib = _ffi.load()
+    rng = np.random.default_rng(4)
+    for name, img in (("t8.tif", rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)), ("t16.tif", rng.integers(0, 65536, (20, 45, 3), dtype=np.uint16)),
+                      ("tg.tif", rng.integers(0, 256, (33, 17), dtype=np.uint8)), ("ta.tif", rng.integers(0, 256, (19, 40, 4), dtype=np.uint8))):
+        write_tiff_tiled(tmp_path / name, img)
+        st, got = _imread(lib, tmp_path / name)
+        assert st == 0 and got.dtype == img.dtype and np.array_equal(got, img), name
+
+
+def test_imread_bmp(tmp_path, write_bmp):
+    """Round 4: BMP without a library — 24-bit (bottom-up and top-down, padded rows), 32-bit -> B G R A, 8-bit colour and grey palettes."""
+    lib = _ffi.load()
+    rng = np.random.default_rng(6)
+    c24 = rng.integers(0, 256, (11, 13, 3), dtype=np.uint8)
+    for td in (False, True):
+        write_bmp(tmp_path / "c.bmp", c24, top_down=td)
+        st, got = _imread(lib, tmp_path / "c.bmp")
+        assert st == 0 and np.array_equal(got, c24)
+    c32 = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    write_bmp(tmp_path / "a.bmp", c32)
+    st, got = _imread(lib, tmp_path / "a.bmp")
+    assert st == 0 and np.array_equal(got, c32)
+    idx = rng.integers(0, 6, (9, 10), dtype=np.uint8)
+    pal = rng.integers(0, 256, (6, 3), dtype=np.uint8)
+    write_bmp(tmp_path / "p.bmp", idx, palette=pal)
+    st, got = _imread(lib, tmp_path / "p.bmp")
+    assert st == 0 and np.array_equal(got, pal[idx])
+    gpal = np.repeat(rng.integers(0, 256, (6, 1), dtype=np.uint8), 3, axis=1)
+    write_bmp(tmp_path / "g.bmp", idx, palette=gpal)
+    st, got = _imread(lib, tmp_path / "g.bmp")
+    assert st == 0 and got.ndim == 2 and np.array_equal(got, gpal[idx][..., 0])
+    data = (tmp_path / "c.bmp").read_bytes()
+    (tmp_path / "short.bmp").write_bytes(data[:100])
+    assert _imread(lib, tmp_path / "short.bmp")[0] == 4                   # truncated: BACKEND_ERROR
+    (tmp_path / "rle.bmp").write_bytes(data[:30] + (1).to_bytes(4, "little") + data[34:])
+    assert _imread(lib, tmp_path / "rle.bmp")[0] == 7                     # RLE8 flag on a 24-bit file: a flavour not taken

@@ -22,7 +22,7 @@ def _build(src, out, flags):
 
 
 @pytest.mark.timeout(600)
-def test_imread_under_asan_ubsan(tmp_path, write_png, write_tiff):
+def test_imread_under_asan_ubsan(tmp_path, write_png, write_tiff, write_tiff_tiled, write_bmp):
     exe = str(tmp_path / "imread_harness")
     _build("imread_harness.cpp", exe, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])
     rng = np.random.default_rng(0)
@@ -37,6 +37,13 @@ def test_imread_under_asan_ubsan(tmp_path, write_png, write_tiff):
     write_png(tmp_path / "ok.png", img); files.append(tmp_path / "ok.png")
     write_tiff(tmp_path / "ok.tif", img); files.append(tmp_path / "ok.tif")
     write_tiff(tmp_path / "ok16.tif", rng.integers(0, 65536, (6, 7, 3), dtype=np.uint16)); files.append(tmp_path / "ok16.tif")
+    # round 4: tiled and RGBA TIFF, RGBA PNG, BMP (24-bit, 32-bit, palette)
+    write_tiff_tiled(tmp_path / "tiled.tif", img); files.append(tmp_path / "tiled.tif")
+    write_tiff_tiled(tmp_path / "tiled_a.tif", rng.integers(0, 256, (9, 21, 4), dtype=np.uint8)); files.append(tmp_path / "tiled_a.tif")
+    write_png(tmp_path / "rgba.png", rng.integers(0, 256, (5, 6, 4), dtype=np.uint8)); files.append(tmp_path / "rgba.png")
+    write_bmp(tmp_path / "ok.bmp", img); files.append(tmp_path / "ok.bmp")
+    write_bmp(tmp_path / "ok32.bmp", rng.integers(0, 256, (4, 5, 4), dtype=np.uint8)); files.append(tmp_path / "ok32.bmp")
+    write_bmp(tmp_path / "okp.bmp", rng.integers(0, 5, (6, 9), dtype=np.uint8), palette=rng.integers(0, 256, (5, 3), dtype=np.uint8)); files.append(tmp_path / "okp.bmp")
     n_good = len(files)
     # truncations at every interesting place and byte-level garbage of each format
     for src in list(files):

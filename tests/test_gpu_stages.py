@@ -38,7 +38,7 @@ def test_gaussian_blur_small_kernels_bit_exact(stacker, ksize):
     assert np.array_equal(stacker.gaussian_blur_f32(g, ksize), oracle.gaussian_blur_f32(g, ksize))
 
 
-@pytest.mark.parametrize("ksize", [9, 15, 31])
+@pytest.mark.parametrize("ksize", [9, 15, 31, 33, 63])
 def test_gaussian_blur_large_kernels(stacker, ksize):
     g = _rng_img(90, 140, 1, np.uint8, 3)[..., 0]
     got, ref = stacker.gaussian_blur_f32(g, ksize), oracle.gaussian_blur_f32(g, ksize)
