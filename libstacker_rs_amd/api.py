@@ -285,6 +285,8 @@ class Stacker:
     # -- whole-stack API (the reference's two entry points) ---------------------------------------
     def ecc_match(self, files, params: EccMatchParameters, scale_down_width: Optional[float] = None,
                   return_stats: bool = False):
+        if isinstance(files, (list, tuple)) and len({tuple(f.shape[:2]) for f in files}) > 1:
+            raise OpenCvError("the frames differ in size: the reference fails on such a stack in cv::add (lib.rs:809)")
         m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")

@@ -159,8 +159,12 @@ def test_keypoint_match_errors(stacker, kp_stack):
         stacker.keypoint_match([f.astype(np.uint16) for f in frames[:2]], PARAMS)      # ORB needs 8-bit
     with pytest.raises(InvalidParams):
         stacker.keypoint_match(list(frames[:2]), PARAMS, scale_down_width=640.0)        # >= full width, lib.rs:377
-    with pytest.raises(InvalidParams):
-        stacker.keypoint_match([frames[0], frames[1][:100]], PARAMS)                   # mismatched sizes
+    # frames of differing SIZE are a legal stack on this path since round 4 (lib.rs:200-204, 290-299: tests/test_gpu_mixed.py);
+    # frames of differing TYPE are not
+    d, out = stacker.keypoint_match([frames[0], np.ascontiguousarray(frames[1][:400])], PARAMS)
+    assert out.shape == frames[0].shape
+    with pytest.raises(OpenCvError):
+        stacker.keypoint_match([frames[0], np.ascontiguousarray(np.concatenate([frames[1][:400], frames[1][:400, :, :1]], -1))], PARAMS)
 
 
 def test_keypoint_match_border_mode_and_value(stacker, kp_stack):
