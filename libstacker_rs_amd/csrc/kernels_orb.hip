@@ -383,6 +383,9 @@ constexpr int FT_TH = FT_Y + 2 * FT_H;               // 40 rows
 constexpr int FT_SW = FT_X + 4, FT_SH = FT_Y + 2;    // score region 130 x 34, stored with a row stride of 132
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+#ifndef STK_FAST_SWAR
+#define STK_FAST_SWAR 1
+#endif
 __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {       // v_pk_sub_i16
     return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
 }
@@ -501,6 +504,35 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
             // exact ring test of pass 2 decides either way: same corners, same bits.
             // centre - tap > thr  <=>  tap < centre - thr: the sign of tap - lo; centre - tap < -thr  <=>  the sign of hi - tap
             // (16-bit lanes: all operands are within [-255, 510]). One subtraction per tap and side.
+#if STK_FAST_SWAR
+            // Round 4: the same eight tests per pixel on PLAIN 32-bit adds. A packed 16-bit subtraction, a v_perm unpack and
+            // a v_alignbyte each occupy the SIMD twice as long as a 32-bit add / and / shift (tools/valu_rates.hip), and this
+            // pass is the largest part of a kernel bound by vector issue. Pixels 0, 2 of the dword (even bytes) and pixels
+            // 1, 3 (odd bytes) go into the two 16-bit halves of a register by and / shift; every operand gets a bias of 1024
+            // per half so that no difference goes negative and a 32-bit add never carries from one half into the other:
+            //   tap < centre - thr  <=>  tap + (1024 + thr - centre) < 1024  <=>  bit 10 of the half is CLEAR   (dark side)
+            //   tap > centre + thr  <=>  (1024 + thr + centre) - tap < 1024  <=>  bit 10 CLEAR                   (bright side)
+            // (halves stay within [769, 1534 + thr] for thr <= 255). The corner condition on the inverted bits:
+            //   (d0 | d2) & (d1 | d3) | (b0 | b2) & (b1 | b3)  =  ~( ((~d0 & ~d2) | (~d1 & ~d3)) & ((~b0 & ~b2) | (~b1 & ~b3)) ).
+            const uint32_t BIAS = 0x04000400u, M8 = 0x00ff00ffu;
+            const uint32_t taps[4] = {nn, ee, ss, ww};
+            uint32_t r[2];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const uint32_t C = (half ? c0 >> 8 : c0) & M8;
+                const uint32_t A = (BIAS + T2) - C, B = (BIAS + T2) + C;
+                uint32_t nd[4], nb[4];                                   // bit 10 / 26 set: the test FAILS for that pixel
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t t = (half ? taps[d] >> 8 : taps[d]) & M8;
+                    nd[d] = t + A;
+                    nb[d] = B - t;
+                }
+                r[half] = ~(((nd[0] & nd[2]) | (nd[1] & nd[3])) & ((nb[0] & nb[2]) | (nb[1] & nb[3])));
+            }
+            // bit 10 of r[0]: pixel 0, bit 26: pixel 2; r[1]: pixels 1 and 3 -> bits 0 .. 3
+            uint32_t m = ((r[0] >> 10) & 1u) | ((r[1] >> 9) & 2u) | ((r[0] >> 24) & 4u) | ((r[1] >> 23) & 8u);
+#else
             uint32_t r[2];
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -525,6 +557,7 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
             // sign bits of r[0] (pixels 0, 1) and r[1] (pixels 2, 3) -> bits 0 .. 3
             const uint32_t sg = ((r[0] & 0x80008000u) >> 15) | ((r[1] & 0x80008000u) >> 13);      // bits 0, 16 | 2, 18
             uint32_t m = (sg | (sg >> 15)) & 0xfu;
+#endif
             // pixel k of this dword: sx = 4 dq - 3 + k in [0, FT_X + 2), image x = x0 - 4 + 4 dq + k in [3, w - 3), y likewise
             uint32_t vm;
             if (interior) vm = act ? (dq == 0 ? 0x8u : dq == ROW_DW - 1 ? 0x1u : 0xfu) : 0u;          // wave-uniform branch
