@@ -588,11 +588,28 @@ __device__ __forceinline__ void fast_nms_tiled_body(const uint8_t* __restrict__ 
     for (int i = tid; i < cntA; i += 256) {
         const int id = listA[i], sy = id / FT_SW, sx = id - sy * FT_SW;
         const uint8_t* p = T + (sy + 3) * FT_TW + sx + 3;
+#if STK_FAST_SWAR
+        // the sixteen ring tests on plain adds, two ring pixels (k and k + 8) per register, biased like pass 1: bit 10 / 26 of
+        // ring + (1024 + thr - centre) is CLEAR where centre - ring > thr, of (1024 + thr + centre) - ring where centre - ring < -thr
+        const uint32_t v = p[0];
+        const uint32_t A2 = (1024u + (uint32_t)thr - v) * 0x00010001u, B2 = (1024u + (uint32_t)thr + v) * 0x00010001u;
+        const int ro[16] = {3 * FT_TW, 3 * FT_TW + 1, 2 * FT_TW + 2, FT_TW + 3, 3, -FT_TW + 3, -2 * FT_TW + 2, -3 * FT_TW + 1,
+                            -3 * FT_TW, -3 * FT_TW - 1, -2 * FT_TW - 2, -FT_TW - 3, -3, FT_TW - 3, 2 * FT_TW - 2, 3 * FT_TW - 1};   // fast_ring's order
+        uint32_t accd = 0, accb = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t reg = (uint32_t)p[ro[j]] | ((uint32_t)p[ro[j + 8]] << 16);
+            accd |= ((reg + A2) >> (10 - j)) & (0x00010001u << j);
+            accb |= ((B2 - reg) >> (10 - j)) & (0x00010001u << j);
+        }
+        const uint32_t md = ~((accd & 0xffu) | ((accd >> 8) & 0xff00u)) & 0xffffu, mb = ~((accb & 0xffu) | ((accb >> 8) & 0xff00u)) & 0xffffu;
+#else
         int d[16];
         fast_ring(p, FT_TW, (int)p[0], d);
         uint32_t md = 0, mb = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) { md |= (uint32_t)(d[k] > thr) << k; mb |= (uint32_t)(d[k] < -thr) << k; }
+#endif
         if (has_arc9(md) || has_arc9(mb)) listB[atomicAdd(&nB, 1)] = (unsigned short)id;
     }
     __syncthreads();

@@ -10,6 +10,7 @@ for r in 1 2; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d.get('roofline', {})
-print('$l', 'ms_per_step', d['ms_per_step'], 'value', d['value'], 'ecc_launch_ms', r.get('avg_launch_ms'), 'align', d['stages'].get('align_ms_per_step'), 'fold', d['stages'].get('warp_ms_per_step'))"
+ks = {k['kernel'][:12]: k['ms_per_step'] for k in d.get('kernels', [])}
+print('$l', 'ms_per_step', d['ms_per_step'], 'value', d['value'], 'ecc_launch_ms', r.get('avg_launch_ms'), 'align', d['stages'].get('align_ms_per_step'), 'fold', d['stages'].get('warp_ms_per_step'), 'kernels', ks)"
   done
 done
