@@ -77,6 +77,7 @@ struct stk_ctx {
     const void* ref_zeroed_ptr = nullptr;   // the frame-0 planes' zero border exists for this buffer and geometry (ecc_prepare_reference)
     int ref_zeroed_w = 0, ref_zeroed_h = 0;
     std::vector<hipEvent_t> prof_ev;   // event pairs for per-launch timing (option profile = 2)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_ev;   // event pairs around the keypoint path's fold launches (grow-only pool)
     // page-locked host block the path-based entry points decode a stack into (imread.cpp: match_files); grow-only, like the
     // device workspaces: locking 6.4 GB of pages for a 256-frame 4K stack costs more than decoding into them
     unsigned char* files_block = nullptr; size_t files_block_cap = 0; bool files_block_pinned = false;

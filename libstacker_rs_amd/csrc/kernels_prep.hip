@@ -366,7 +366,13 @@ __global__ __launch_bounds__(256) void grey_blur_u8c3_kernel(const T* __restrict
 // row results in registers and column-filters one output row per step (one float4 store). Rows are prefetched GS_PF
 // deep. Same arithmetic in the same order as the tiled kernel: bit-identical planes. Enough waves to fill the chip come
 // from batching the frames of a shard (blockIdx.z); single frames keep the tiled kernel.
-constexpr int GS_SEG = 32, GS_PF = 4, GS_QW = 62;         // output rows per segment, rows in flight, output quads per wave
+#ifndef GS_SEG_OVERRIDE
+#define GS_SEG_OVERRIDE 32
+#endif
+#ifndef GS_PF_OVERRIDE
+#define GS_PF_OVERRIDE 4
+#endif
+constexpr int GS_SEG = GS_SEG_OVERRIDE, GS_PF = GS_PF_OVERRIDE, GS_QW = 62;         // output rows per segment, rows in flight, output quads per wave
 
 template <typename T> struct QuadRaw;
 template <> struct QuadRaw<uint8_t> { uint32_t d[3]; };

@@ -825,13 +825,17 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     // that lane and every earlier one are through, while later lanes are still in their host steps. Launches accumulate in
     // stack order, so the f32 sum is the one a single launch over all frames gives (each pixel: ((0 + f_a) + f_b) + ...).
     std::vector<WarpFrame> wf(n);                               // entries [0, n_wf) are used; never reallocated (async copies read it)
-    struct StreamIdle { hipStream_t s; ~StreamIdle() { (void)hipStreamSynchronize(s); } } wf_outlives_its_copies{ctx->stream};
     int n_wf = 0, dropped = 0;
     const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     HIP_TRY(ctx->warpframes.reserve(sizeof(WarpFrame) * (size_t)n));
     const bool timed = ctx->opt_profile >= 1;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_ev;
-    struct EvGuard { std::vector<std::pair<hipEvent_t, hipEvent_t>>& v; ~EvGuard() { for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } } } fold_ev_guard{fold_ev};
+    // The fold's event pairs come from a pool the context keeps (two hipEventCreate per lane on every call sat
+    // inside the lanes' critical section); `used` of them belong to this call.
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>& fold_ev = ctx->fold_ev;
+    size_t fold_used = 0;
+    // Declared LAST among the guards, so that it runs FIRST on every way out: nothing of this call is still queued on the
+    // stream when `wf` (read by asynchronous copies) or anything else above goes away.
+    struct StreamIdle { hipStream_t s; ~StreamIdle() { (void)hipStreamSynchronize(s); } } wf_outlives_its_copies{ctx->stream};
     const KpFramesFinal fold_range = [&](int lo, int hi) -> stk_status {
         (void)hipSetDevice(ctx->device);
         const int first = n_wf;
@@ -844,16 +848,18 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
         if (cnt == 0) return STK_OK;
         for (int k = first; k < n_wf; k++) wf[k].flags = warp_frame_flags(wf[k].src, wf[k].M, rb, w, h, 0);
         if (timed) {
-            hipEvent_t a = nullptr, b = nullptr;
-            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-            fold_ev.emplace_back(a, b);
-            HIP_TRY(hipEventRecord(a, ctx->stream));
+            if (fold_used == fold_ev.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+                fold_ev.emplace_back(a, b);
+            }
+            HIP_TRY(hipEventRecord(fold_ev[fold_used].first, ctx->stream));
         }
         HIP_TRY(hipMemcpyAsync(ctx->warpframes.as<WarpFrame>() + first, wf.data() + first, sizeof(WarpFrame) * (size_t)cnt, hipMemcpyHostToDevice, ctx->stream));
         const stk_status fs = warp_fold_enqueue(ctx, cnt, 8, w, h, cn, rb, 1.0 / 255.0, params->border_mode, params->border_value, 0, sum->data,
                                                 image_stride_floats(sum), first > 0 ? 1 : 0, first);
         if (fs) return fs;
-        if (timed) HIP_TRY(hipEventRecord(fold_ev.back().second, ctx->stream));
+        if (timed) { HIP_TRY(hipEventRecord(fold_ev[fold_used].second, ctx->stream)); fold_used++; }
         return STK_OK;
     };
     if ((st = keypoint_align_impl(ctx, frames, params, scale_down_width, false, results, &n0, dev, &fold_range))) return st;
@@ -871,7 +877,7 @@ stk_status stk_keypoint_match_shard(stk_ctx* ctx, const stk_frames* frames, cons
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->timing.align_ms = ev_ms(ctx->ev[0], ctx->ev[1]);       // includes the folds that ran under later lanes
     ctx->timing.warp_ms = 0;
-    for (auto& p : fold_ev) ctx->timing.warp_ms += ev_ms(p.first, p.second);
+    for (size_t k = 0; k < fold_used; k++) ctx->timing.warp_ms += ev_ms(fold_ev[k].first, fold_ev[k].second);
     if (n_added) *n_added = (int32_t)n_wf;
     if (n_dropped) *n_dropped = dropped;
     return STK_OK;

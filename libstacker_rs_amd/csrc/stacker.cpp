@@ -100,6 +100,7 @@ void stk_destroy(stk_ctx* ctx) {
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->prof_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& pr : ctx->fold_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->host_done) (void)hipHostFree(ctx->host_done);
     if (ctx->files_block) { if (ctx->files_block_pinned) (void)hipHostFree(ctx->files_block); else std::free(ctx->files_block); }
     for (auto& e : ctx->upload_events) if (e) (void)hipEventDestroy(e);

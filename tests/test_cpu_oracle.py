@@ -336,3 +336,79 @@ def test_gradients_match_scipy_correlate():
     k = np.array([-0.5, 0.0, 0.5])
     assert np.max(np.abs(gx - correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"))) <= 1e-4
     assert np.max(np.abs(gy - correlate1d(img.astype(np.float64), k, axis=0, mode="mirror"))) <= 1e-4
+
+
+def test_orb_harris_response_and_angle_match_scipy():
+    """ORB's per-keypoint Harris response and intensity-centroid angle, recomputed for the oracle's level-0 keypoints with
+    scipy / numpy from the textbook definitions (Sobel 3x3 gradients, 7x7 box sums, det - 0.04 trace^2 scaled by
+    (1 / (4 * 7 * 255))^4; first-order moments over the radius-15 disc, atan2 in degrees). Independent of the oracle's code
+    path for these two quantities; says nothing about FAST, the pyramid or BRIEF."""
+    from scipy.ndimage import correlate
+    from libstacker_rs_amd import synth
+    frames, _ = synth.make_stack(1, 640, 480)
+    g = oracle.grey(frames.numpy()[0])
+    kp, de = oracle.orb_detect_and_compute(g)
+    lvl0 = kp[kp[:, 5] == 0]
+    assert len(lvl0) >= 50
+    I = g.astype(np.int64)
+    sx = correlate(I, np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]), mode="constant")
+    sy = correlate(I, np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]]), mode="constant")
+    box = np.ones((7, 7), np.int64)
+    a, b, c = correlate(sx * sx, box, mode="constant"), correlate(sy * sy, box, mode="constant"), correlate(sx * sy, box, mode="constant")
+    scale4 = np.float32(1.0 / (4 * 7 * 255.0)) ** 4
+    # the radius-15 disc: u_max per row as ORB builds it (rounded quarter circle, made symmetric about the diagonal)
+    hp = 15
+    vmax, vmin = int(np.floor(hp * np.sqrt(2) / 2 + 1)), int(np.ceil(hp * np.sqrt(2) / 2))
+    umax = np.zeros(hp + 2, int)
+    for v in range(vmax + 1):
+        umax[v] = int(np.rint(np.sqrt(hp * hp - v * v)))
+    v0 = 0
+    for v in range(hp, vmin - 1, -1):
+        while umax[v0] == umax[v0 + 1]:
+            v0 += 1
+        umax[v] = v0
+        v0 += 1
+    worst_r = worst_a = 0.0
+    for x, y, size, angle, resp in lvl0[:, :5]:
+        xi, yi = int(x), int(y)
+        assert (xi, yi) == (x, y) and size == 31.0
+        fa, fb, fc = np.float32(a[yi, xi]), np.float32(b[yi, xi]), np.float32(c[yi, xi])
+        r = (fa * fb - fc * fc - np.float32(0.04) * (fa + fb) * (fa + fb)) * scale4
+        worst_r = max(worst_r, abs(float(r) - resp) / max(abs(resp), 1e-12))
+        m10 = m01 = 0
+        for v in range(-hp, hp + 1):
+            u = umax[abs(v)]
+            row = I[yi + v, xi - u:xi + u + 1]
+            m10 += int(np.dot(np.arange(-u, u + 1), row))
+            m01 += v * int(row.sum())
+        ref = np.degrees(np.arctan2(m01, m10)) % 360.0
+        worst_a = max(worst_a, min(abs(ref - angle), 360.0 - abs(ref - angle)))
+    assert worst_r <= 2e-6, worst_r            # f32 evaluation order of the determinant
+    assert worst_a <= 0.35, worst_a            # fastAtan2 is a 0.3-degree polynomial
+
+
+def test_fast_score_map_matches_the_definition():
+    """FAST-9/16 from its definition, by brute force over thresholds: a pixel is a corner at threshold t iff nine contiguous
+    pixels of the 16-pixel Bresenham ring are all brighter than centre + t or all darker than centre - t; its score is the
+    largest t >= threshold for which it still is one (OpenCV's cornerScore), 0 for non-corners."""
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (40, 56)).astype(np.uint8)
+    img[10:30, 20:40] = np.clip(img[10:30, 20:40].astype(int) + 90, 0, 255).astype(np.uint8)     # a bright block: real corners
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    h, w = img.shape
+    I = img.astype(int)
+    ref = np.zeros((h, w), int)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = np.array([I[y + dy, x + dx] - I[y, x] for dx, dy in ring])
+            best = 0
+            for t in range(20, 256):
+                br, dk = d > t, d < -t
+                ok = any(all(br[(k + j) % 16] for j in range(9)) or all(dk[(k + j) % 16] for j in range(9)) for k in range(16))
+                if not ok:
+                    break
+                best = t
+            ref[y, x] = best
+    got = oracle.fast_score_map(img, 20).astype(int)
+    assert np.array_equal(got[3:h - 3, 3:w - 3], ref[3:h - 3, 3:w - 3])
+    assert (ref > 0).sum() > 20
