@@ -482,14 +482,8 @@ hipError_t launch_warp_frames_from_ecc(const EccFrameResult* results, const void
     return hipGetLastError();
 }
 
-hipError_t launch_warp_accumulate_tile(const WarpArgs& a, int depth, hipStream_t s);   // kernels_warp_tile.hip
-
 hipError_t launch_warp_accumulate(const WarpArgs& a, int depth, hipStream_t s) {
     dim3 grid((a.dw + 63) / 64, (a.dh + 3) / 4);
-    // option "warp_tune" bit 8: the tile kernel (source window converted once per tile, taps from LDS)
-    if ((a.tune & 0x100) && (depth == 8 || depth == 16) && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT &&
-        a.sw >= 8 && a.sh >= 2 && a.src_stride < (1u << 23))
-        return launch_warp_accumulate_tile(a, depth, s);
     // (sh >= 2: the kernel's interior bound is (unsigned)(sh - 2); a one-row frame takes the generic kernel)
     if (depth == 8 && a.cn == 3 && a.subpixel_bits == 0 && a.border_mode == STK_BORDER_CONSTANT && a.sw >= 2 && a.sh >= 2 &&
         (size_t)a.sw * a.sh * 3 >= 16 && a.src_stride * (size_t)a.sh < ((size_t)1 << 31) && a.src_stride < (1u << 23) && a.sh < (1 << 23)) {

@@ -162,17 +162,8 @@ def test_warp_degenerate_matrix_gives_border(stacker):
     assert np.array_equal(got, ref) and not np.isnan(got).any()
 
 
-@pytest.fixture(params=[0, 0x100], ids=["gather", "tile"])
-def warp_route(request, stacker):
-    """Both fast routes of the fold: the per-pixel gather kernels (kernels_warp.hip) and the tile kernel that converts a
-    tile's source window once into LDS (kernels_warp_tile.hip, round 4; option warp_tune bit 8)."""
-    stacker.set_option("warp_tune", request.param)
-    yield request.param
-    stacker.set_option("warp_tune", 0)
-
-
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
-def test_warp_u8_fast_path_is_bit_identical_to_the_generic_kernel(stacker, dtype, warp_route):
+def test_warp_u8_fast_path_is_bit_identical_to_the_generic_kernel(stacker, dtype):
     """warp_accumulate_u8c3_kernel (and its 16-bit sibling) shares one reciprocal chain between X / W and Y / W (the compiler's own IEEE expansion
     without the range scaling) and skips clamps and border selects on interior waves: wherever all four taps are inside
     the frame it must return the very bits of the generic kernel (true `/`, per-tap selects), which BORDER_REPLICATE selects."""
@@ -208,7 +199,7 @@ def _fast_path_vs_generic(stacker, dtype, h, w):
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
-def test_warp_fast_paths_equal_the_generic_kernel_everywhere_also_for_non_finite_maps(stacker, dtype, warp_route):
+def test_warp_fast_paths_equal_the_generic_kernel_everywhere_also_for_non_finite_maps(stacker, dtype):
     """BORDER_CONSTANT on every pixel, rim and border included: the u8 / u16 fast kernels against the generic kernel, which
     the same pixel values reach as a float32 frame. Also for maps with inf / NaN coordinates (a NaN X or Y with
     a finite W once passed the fast path's range test, v_max drops NaN operands, and accumulated NaN; OpenCV's
