@@ -289,9 +289,9 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
  * (libtiff.so.5 / .6), the libraries loaded at run time: BGR(A) or grey rows, tightly packed, into `data` (capacity_bytes);
  * data == NULL only reports the geometry. ctx may be NULL. A file that is unreadable or not an image: STK_BACKEND_ERROR (the
  * reference's empty Mat + cvtColor). TIFF may be stripped or tiled, RGBA TIFF gives four channels; BMP (no library:
- * uncompressed 24-bit, 32-bit -> B G R A, 8-bit palette -> BGR or grey). Flavours no decoder here takes (CMYK JPEG, planar
- * TIFF, RLE / 1- / 4- / 16-bit BMP, WebP / EXR ...): STK_NOT_IMPLEMENTED — the caller decodes those itself and uses the
- * frame-based entry points. */
+ * uncompressed 24-bit, 32-bit -> B G R A, 8-bit palette -> BGR or grey); still WebP (libwebp.so.7: BGR, or B G R A when the
+ * bitstream has alpha). Flavours no decoder here takes (CMYK JPEG, planar TIFF, RLE / 1- / 4- / 16-bit BMP, animated WebP,
+ * EXR / JPEG 2000 ...): STK_NOT_IMPLEMENTED — the caller decodes those itself and uses the frame-based entry points. */
 stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width,
                       int32_t* height, int32_t* channels, int32_t* depth);
 /* keypoint_match / ecc_match in the reference's own call shape: a list of file paths, first = reference frame

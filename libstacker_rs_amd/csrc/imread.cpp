@@ -4,8 +4,9 @@
 // (8- and 16-bit grey / RGB, palette -> BGR, 1/2/4-bit grey -> 8 bit: libpng's row API, samples as stored, never
 // gamma-converted), JPEG (grey / YCbCr: libjpeg-turbo at its default settings, OpenCV's decoder family) and stripped 8/16-bit
 // grey / RGB TIFF (libtiff's handle API) through libpng16.so.16 / libjpeg.so.8 / libtiff.so.5 loaded at run time — the image
-// has the libraries but not their headers, so the entry points used are declared below. What the build does not take
-// (PNG with alpha or tRNS: the reference would stack four channels; tiled or compressed-planar TIFF; CMYK JPEG) returns
+// has the libraries but not their headers, so the entry points used are declared below. Round 4: PNG with alpha or tRNS and
+// RGBA TIFF decode to four channels as the reference's imread does, tiled TIFF, uncompressed BMP, still WebP (libwebp.so.7).
+// What the build does not take (separate-plane TIFF; CMYK JPEG; animated WebP; EXR / JPEG 2000) returns
 // STK_NOT_IMPLEMENTED and the caller decodes it itself (the frame-based entry points are the boundary). A file that is
 // missing or not an image behaves as in the reference: imread gives an empty Mat and the following cvtColor raises ->
 // STK_BACKEND_ERROR (OpenCvError).
@@ -398,6 +399,49 @@ int bmp_load(const std::vector<unsigned char>& f, Pnm& p, std::vector<unsigned c
     return 0;
 }
 
+// ---- WebP through libwebp's simple decoding API (libwebp.so.7), resolved at run time -------------------------------------
+// OpenCV's WebPDecoder [OCV-RECALL: grfmt_webp.cpp] asks WebPGetFeatures for the geometry, gives the Mat four channels when
+// the bitstream has alpha and three otherwise (IMREAD_UNCHANGED), and decodes with WebPDecodeBGRAInto / WebPDecodeBGRInto:
+// the same two calls here, so the pixels are the library's own. Animated files: not taken.
+struct WebPFeatures { int width, height, has_alpha, has_animation, format; uint32_t pad[5]; };   // WebPBitstreamFeatures (decode.h, ABI 0x02xx)
+static_assert(sizeof(WebPFeatures) == 40, "WebPBitstreamFeatures layout");
+struct WebPApi {
+    int (*get_features)(const uint8_t*, size_t, WebPFeatures*, int) = nullptr;                  // WebPGetFeaturesInternal -> VP8StatusCode
+    uint8_t* (*bgr_into)(const uint8_t*, size_t, uint8_t*, size_t, int) = nullptr;
+    uint8_t* (*bgra_into)(const uint8_t*, size_t, uint8_t*, size_t, int) = nullptr;
+    bool ok = false;
+};
+const WebPApi& webp_api() {
+    static const WebPApi api = [] {
+        WebPApi a;
+        void* h = dlopen("libwebp.so.7", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.get_features = reinterpret_cast<decltype(a.get_features)>(dlsym(h, "WebPGetFeaturesInternal"));
+        a.bgr_into = reinterpret_cast<decltype(a.bgr_into)>(dlsym(h, "WebPDecodeBGRInto"));
+        a.bgra_into = reinterpret_cast<decltype(a.bgra_into)>(dlsym(h, "WebPDecodeBGRAInto"));
+        a.ok = a.get_features && a.bgr_into && a.bgra_into;
+        return a;
+    }();
+    return api;
+}
+
+// 0 decoded (BGR or BGRA, 8 bit); 1 not decodable; 2 a flavour / library this build does not take
+int webp_load(const std::vector<unsigned char>& f, Pnm& p, std::vector<unsigned char>& pix) {
+    const WebPApi& api = webp_api();
+    if (!api.ok) return 2;
+    WebPFeatures ft{};
+    const int st = api.get_features(f.data(), f.size(), &ft, 0x0209);           // WEBP_DECODER_ABI_VERSION of the 1.x series
+    if (st == 2) return 2;                                                      // VP8_STATUS_INVALID_PARAM: another ABI
+    if (st != 0 || ft.width <= 0 || ft.height <= 0 || ft.width > 16383 || ft.height > 16383) return 1;
+    if (ft.has_animation) return 2;
+    const int cn = ft.has_alpha ? 4 : 3;
+    pix.resize((size_t)ft.width * ft.height * cn);
+    uint8_t* got = (cn == 4 ? api.bgra_into : api.bgr_into)(f.data(), f.size(), pix.data(), pix.size(), ft.width * cn);
+    if (got != pix.data()) return 1;
+    p.w = ft.width; p.h = ft.height; p.cn = cn; p.depth = 8; p.data_ofs = 0;
+    return 0;
+}
+
 // ---- JPEG through libjpeg-turbo's classic API (libjpeg.so.8), resolved at run time --------------------------------------
 // The reference's own data set is JPEG (README.md:18, examples/main.rs:35) and OpenCV decodes it with this very library
 // family at its default settings (JDCT_ISLOW, fancy upsampling), which is what is requested here, so the pixels are
@@ -613,9 +657,18 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
         return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only grey / YCbCr JPEG through libjpeg-turbo's libjpeg.so.8 is decoded "
                                               "in this build (library " + (jpeg_api().ok ? "loaded" : "not found") + "); decode it on the caller's side");
     }
-    for (const char* e : {".bmp", ".webp", ".exr"})
+    if (has_ext(path, ".webp")) {
+        std::vector<unsigned char> raw;
+        if (!read_file(path, raw)) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot read '") + path + "' (empty Mat -> cvtColor fails)");
+        const int rc = webp_load(raw, p, file);
+        if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }
+        if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only still WebP through libwebp.so.7 is decoded in this build (library " +
+                                              (webp_api().ok ? "loaded" : "not found") + ")");
+    }
+    for (const char* e : {".exr", ".jp2", ".hdr"})
         if (has_ext(path, e))
-            return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: no codec for '") + path + "' in this build (binary PNM only); decode it "
+            return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: no codec for '") + path + "' in this build; decode it "
                                                   "on the caller's side and use the frame-based entry points");
     if (!read_file(path, file)) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot read '") + path + "' (empty Mat -> cvtColor fails)");
     const int rc = pnm_header(file.data(), file.size(), p);

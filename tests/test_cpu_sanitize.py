@@ -44,6 +44,20 @@ def test_imread_under_asan_ubsan(tmp_path, write_png, write_tiff, write_tiff_til
     write_bmp(tmp_path / "ok.bmp", img); files.append(tmp_path / "ok.bmp")
     write_bmp(tmp_path / "ok32.bmp", rng.integers(0, 256, (4, 5, 4), dtype=np.uint8)); files.append(tmp_path / "ok32.bmp")
     write_bmp(tmp_path / "okp.bmp", rng.integers(0, 5, (6, 9), dtype=np.uint8), palette=rng.integers(0, 256, (5, 3), dtype=np.uint8)); files.append(tmp_path / "okp.bmp")
+    try:                                                   # still WebP (lossless colour, lossless with alpha, lossy), when the machine has the library
+        import ctypes as C
+        wl = C.CDLL("libwebp.so.7")
+        for name, arr, fn, extra in (("ok.webp", img, "WebPEncodeLosslessBGR", ()), ("oka.webp", rng.integers(1, 256, (7, 9, 4), dtype=np.uint8), "WebPEncodeLosslessBGRA", ()),
+                                     ("okl.webp", img, "WebPEncodeBGR", (C.c_float(70.0),))):
+            f = getattr(wl, fn); f.restype = C.c_size_t
+            arr = np.ascontiguousarray(arr)
+            out = C.c_void_p()
+            n = f(C.c_void_p(arr.ctypes.data), C.c_int(arr.shape[1]), C.c_int(arr.shape[0]), C.c_int(arr.strides[0]), *extra, C.byref(out))
+            assert n > 0
+            (tmp_path / name).write_bytes(C.string_at(out, n)); files.append(tmp_path / name)
+            wl.WebPFree.argtypes = [C.c_void_p]; wl.WebPFree(out)
+    except OSError:
+        pass
     n_good = len(files)
     # truncations at every interesting place and byte-level garbage of each format
     for src in list(files):
