@@ -336,6 +336,10 @@ stk_status stk_warp_accumulate(stk_ctx* ctx, const stk_frames* frame /* n==1 */,
  * smaller dimension becomes scale_down. out must hold new_w * new_h bytes (<= width * height). */
 stk_status stk_scale_image_grey(stk_ctx* ctx, const uint8_t* grey, int32_t width, int32_t height, int32_t location,
                                 float scale_down, uint8_t* out, int32_t* new_width, int32_t* new_height);
+/* The same on a 32FC1 grey (the grey of a float stack, e.g. float TIFF: ecc_match_scaling_down shrinks whatever depth cvtColor
+ * gave it, lib.rs:896, 921; 16-bit greys never get that far — findTransformECC and ORB reject them first). */
+stk_status stk_scale_image_grey_f32(stk_ctx* ctx, const float* grey, int32_t width, int32_t height, int32_t location,
+                                    float scale_down, float* out, int32_t* new_width, int32_t* new_height);
 
 /* ORB::create_def + detect_and_compute, utils.rs:174-183. keypoints: rows of 7 floats
  * {x, y, size, angle, response, octave, class_id}; descriptors: rows of 32 bytes. */

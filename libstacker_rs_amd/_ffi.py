@@ -108,6 +108,8 @@ SIGNATURES = {
                                        C.c_double, C.c_int32, C.POINTER(ImageF32)]),
     "stk_scale_image_grey": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "stk_scale_image_grey_f32": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stk_orb_detect_and_compute": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "stk_bf_knn2_hamming": (c_status, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

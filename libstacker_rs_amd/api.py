@@ -578,13 +578,15 @@ class Stacker:
         return out
 
     def scale_image_grey(self, grey, scale_down: float):
-        """utils::scale_image (utils.rs:186-214) on an 8-bit grey image: INTER_AREA, smaller dimension -> scale_down."""
-        g = np.ascontiguousarray(grey, np.uint8)
+        """utils::scale_image (utils.rs:186-214) on a grey image, 8-bit or f32 (the depths cvtColor leaves where the reference
+        shrinks a grey): INTER_AREA, smaller dimension -> scale_down."""
+        f32 = np.asarray(grey).dtype == np.float32
+        g = np.ascontiguousarray(grey, np.float32 if f32 else np.uint8)
         h, w = g.shape
-        out = np.empty(h * w, np.uint8)
+        out = np.empty(h * w, g.dtype)
         nw, nh = C.c_int32(0), C.c_int32(0)
-        self._check(self._lib.stk_scale_image_grey(self._h, C.c_void_p(g.ctypes.data), w, h, HOST, float(scale_down),
-                                                   C.c_void_p(out.ctypes.data), C.byref(nw), C.byref(nh)))
+        fn = self._lib.stk_scale_image_grey_f32 if f32 else self._lib.stk_scale_image_grey
+        self._check(fn(self._h, C.c_void_p(g.ctypes.data), w, h, HOST, float(scale_down), C.c_void_p(out.ctypes.data), C.byref(nw), C.byref(nh)))
         return out[: nw.value * nh.value].reshape(nh.value, nw.value).copy()
 
     def orb_detect_and_compute(self, grey, max_keypoints: int = 2000):

@@ -258,7 +258,7 @@ hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst,
     return hipGetLastError();
 }
 
-// ---- scale_image: resize(INTER_AREA) of an 8-bit grey image (utils.rs:186-214) ---------------------------
+// ---- scale_image: resize(INTER_AREA) of a grey image, 8-bit or f32 (utils.rs:186-214) -------------------
 // One thread per destination pixel; it walks the fractional-coverage cells of its source rectangle in the
 // order of OpenCV's computeResizeAreaTab tables (partial left cell, full cells, partial right cell; rows
 // combined as sum = beta0*buf0, sum += beta_k*buf_k), so the f32 result is the same bit pattern.
@@ -280,24 +280,52 @@ __device__ __forceinline__ AreaSpan area_span(int d, int ssize, double scale) {
     return sp;
 }
 
-__global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __restrict__ src, int sw, int sh,
-                                                             uint8_t* __restrict__ dst, int dw, int dh, double scale_x,
-                                                             double scale_y, int isx, int isy) {
+// T = uint8_t: WT = int for integer ratios, cvRound on store; T = float (a 32FC1 grey, e.g. a float TIFF stack): the f32 sum as it is.
+// (16-bit greys never get here: findTransformECC takes 8UC1 / 32FC1 only and ORB 8UC1 only, the reference fails on them first.)
+template <typename T>
+__global__ __launch_bounds__(256) void resize_area_kernel(const T* __restrict__ src, int sw, int sh,
+                                                          T* __restrict__ dst, int dw, int dh, double scale_x,
+                                                          double scale_y, int isx, int isy) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
-    if (isx > 0) {   // integer ratios: resizeAreaFast, cvRound(sum * (1.f / area))
-        int sum = 0;
-        for (int j = 0; j < isy; j++)
-            for (int i = 0; i < isx; i++) sum += src[(size_t)(y * isy + j) * sw + x * isx + i];
-        const int r = (int)__builtin_rintf((float)sum * (1.f / (float)(isx * isy)));
-        dst[(size_t)y * dw + x] = (uint8_t)min(max(r, 0), 255);
+    constexpr bool U8 = sizeof(T) == 1;
+    auto store = [&](float v) {
+        if constexpr (U8) dst[(size_t)y * dw + x] = (uint8_t)min(max((int)__builtin_rintf(v), 0), 255);
+        else dst[(size_t)y * dw + x] = v;
+    };
+    if (isx > 0) {   // integer ratios: resizeAreaFast_ [OCV-RECALL: imgproc/src/resize.cpp]
+        const T* S = src + (size_t)(y * isy) * sw + (size_t)x * isx;
+        if (isx == 2 && isy == 2) {
+            // ResizeAreaFastVec's 2 x 2 special case: 8-bit (a + b + c + d + 2) >> 2 — half rounds UP, unlike cvRound; f32: the
+            // vector form (a + b) + (c + d), times 0.25 (OpenCV's scalar tail of a row, w mod the vector width, adds in the
+            // order ((a + b) + c) + d instead: that last-bit difference on a few right-hand columns is not reproduced)
+            if constexpr (U8) dst[(size_t)y * dw + x] = (uint8_t)(((int)S[0] + S[1] + S[sw] + S[sw + 1] + 2) >> 2);
+            else dst[(size_t)y * dw + x] = ((S[0] + S[1]) + (S[sw] + S[sw + 1])) * 0.25f;
+            return;
+        }
+        const float sc = 1.f / (float)(isx * isy);
+        if constexpr (U8) {
+            int sum = 0;
+            for (int j = 0; j < isy; j++)
+                for (int i = 0; i < isx; i++) sum += S[(size_t)j * sw + i];
+            store((float)sum * sc);
+        } else {
+            // sum += S[ofs[k]] + S[ofs[k + 1]] + S[ofs[k + 2]] + S[ofs[k + 3]] over the cell in row-major order, then one by one
+            const int area = isx * isy;
+            auto at = [&](int k) { const int j = k / isx; return S[(size_t)j * sw + (k - j * isx)]; };
+            float sum = 0.f;
+            int k = 0;
+            for (; k <= area - 4; k += 4) sum += ((at(k) + at(k + 1)) + at(k + 2)) + at(k + 3);
+            for (; k < area; k++) sum += at(k);
+            store(sum * sc);
+        }
         return;
     }
     const AreaSpan sx = area_span(x, sw, scale_x), sy = area_span(y, sh, scale_y);
     float sum = 0.f;
     bool first_row = true;
     auto row = [&](int yy, float beta) {
-        const uint8_t* S = src + (size_t)yy * sw;
+        const T* S = src + (size_t)yy * sw;
         float buf = 0.f;
         if (sx.has_first) buf += (float)S[sx.s1 - 1] * sx.a_first;
         for (int xx = sx.s1; xx < sx.s2; xx++) buf += (float)S[xx] * sx.a_full;
@@ -308,17 +336,21 @@ __global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __re
     if (sy.has_first) row(sy.s1 - 1, sy.a_first);
     for (int yy = sy.s1; yy < sy.s2; yy++) row(yy, sy.a_full);
     if (sy.has_last) row(sy.s2, sy.a_last);
-    const int r = (int)__builtin_rintf(sum);
-    dst[(size_t)y * dw + x] = (uint8_t)min(max(r, 0), 255);
+    store(sum);
 }
 
-hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s) {
+hipError_t launch_resize_area(const void* src, int depth, int sw, int sh, void* dst, int dw, int dh, hipStream_t s) {
+    if (depth != 8 && depth != 32) return hipErrorInvalidValue;
     dim3 grid((dw + 63) / 64, (dh + 3) / 4);
     const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
     const int ix = (int)std::lrint(scale_x), iy = (int)std::lrint(scale_y);
     const bool fast = std::fabs(scale_x - ix) < 2.220446049250313e-16 && std::fabs(scale_y - iy) < 2.220446049250313e-16;
-    resize_area_u8_kernel<<<grid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, scale_x, scale_y, fast ? ix : 0, fast ? iy : 0);
+    if (depth == 8) resize_area_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)src, sw, sh, (uint8_t*)dst, dw, dh, scale_x, scale_y, fast ? ix : 0, fast ? iy : 0);
+    else resize_area_kernel<float><<<grid, 256, 0, s>>>((const float*)src, sw, sh, (float*)dst, dw, dh, scale_x, scale_y, fast ? ix : 0, fast ? iy : 0);
     return hipGetLastError();
+}
+hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s) {
+    return launch_resize_area(src, 8, sw, sh, dst, dw, dh, s);
 }
 
 // ---- FAST -----------------------------------------------------------------------------------------

@@ -428,8 +428,9 @@ stk_status stk_orb_detect_and_compute(stk_ctx* ctx, const uint8_t* grey, int32_t
     return STK_OK;
 }
 
-stk_status stk_scale_image_grey(stk_ctx* ctx, const uint8_t* grey, int32_t width, int32_t height, int32_t location,
-                                float scale_down, uint8_t* out, int32_t* new_width, int32_t* new_height) {
+// scale_image on a grey image of `depth` 8 (8UC1) or 32 (32FC1): the two depths a grey can have where the reference shrinks it
+static stk_status scale_image_grey_impl(stk_ctx* ctx, const void* grey, int depth, int32_t width, int32_t height, int32_t location,
+                                        float scale_down, void* out, int32_t* new_width, int32_t* new_height) {
     if (!ctx) return STK_INVALID_PARAMS;
     if (!grey || !out || width <= 0 || height <= 0 || !new_width || !new_height) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
     int nw, nh;
@@ -437,18 +438,27 @@ stk_status stk_scale_image_grey(stk_ctx* ctx, const uint8_t* grey, int32_t width
         return fail(ctx, STK_BACKEND_ERROR, "resize(INTER_AREA): scale_down must give a non-empty image no larger than the input");
     (void)hipSetDevice(ctx->device);
     KeypointWorkspace* ws = ctx->kp;
-    const size_t ib = (size_t)width * height, ob = (size_t)nw * nh;
-    const uint8_t* src = grey; uint8_t* dst = out;
+    const size_t el = (size_t)depth / 8, ib = (size_t)width * height * el, ob = (size_t)nw * nh * el;
+    const void* src = grey; void* dst = out;
     if (location == STK_HOST) {
         HIP_TRY(ws->gfull.reserve(ib)); HIP_TRY(ws->score.reserve(ob));
         HIP_TRY(hipMemcpyAsync(ws->gfull.p, grey, ib, hipMemcpyHostToDevice, ctx->stream));
-        src = ws->gfull.as<uint8_t>(); dst = ws->score.as<uint8_t>();
+        src = ws->gfull.p; dst = ws->score.p;
     }
-    HIP_TRY(launch_resize_area_u8(src, width, height, dst, nw, nh, ctx->stream));
+    HIP_TRY(launch_resize_area(src, depth, width, height, dst, nw, nh, ctx->stream));
     if (location == STK_HOST) HIP_TRY(hipMemcpyAsync(out, dst, ob, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *new_width = nw; *new_height = nh;
     return STK_OK;
+}
+
+stk_status stk_scale_image_grey(stk_ctx* ctx, const uint8_t* grey, int32_t width, int32_t height, int32_t location,
+                                float scale_down, uint8_t* out, int32_t* new_width, int32_t* new_height) {
+    return scale_image_grey_impl(ctx, grey, 8, width, height, location, scale_down, out, new_width, new_height);
+}
+stk_status stk_scale_image_grey_f32(stk_ctx* ctx, const float* grey, int32_t width, int32_t height, int32_t location,
+                                    float scale_down, float* out, int32_t* new_width, int32_t* new_height) {
+    return scale_image_grey_impl(ctx, grey, 32, width, height, location, scale_down, out, new_width, new_height);
 }
 
 stk_status stk_bf_knn2_hamming(stk_ctx* ctx, const uint8_t* query, int32_t n_query, const uint8_t* train, int32_t n_train,

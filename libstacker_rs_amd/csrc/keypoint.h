@@ -44,6 +44,7 @@ hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst,
 hipError_t launch_resize_tables(int sw, int sh, int dw, int dh, int* tab, hipStream_t s);
 size_t resize_tables_ints(int dw, int dh);
 hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, hipStream_t s);
+hipError_t launch_resize_area(const void* src, int depth, int sw, int sh, void* dst, int dw, int dh, hipStream_t s);   // depth 8 or 32 (f32 grey)
 // scale_image's target size (utils.rs:186-214): the SMALLER dimension becomes scale_down, `as i32` truncation
 inline bool scaled_size(int w, int h, float scale_down, int& nw, int& nh) {
     const double sf = w < h ? (double)scale_down / (double)w : (double)scale_down / (double)h;

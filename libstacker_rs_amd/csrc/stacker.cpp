@@ -514,7 +514,6 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
                                                   std::to_string(w) + ", scale_down_to:" + std::to_string(scale_down_width));
         if (scale_down_width <= 10.0f)      // lib.rs:883-888
             return fail(ctx, STK_INVALID_PARAMS, "scale_down_to was too small scale_down_to:" + std::to_string(scale_down_width));
-        if (frames->depth != 8) return fail(ctx, STK_NOT_IMPLEMENTED, "ecc_match with scale_down_width: only 8-bit frames");
         if (!scaled_size(w, h, scale_down_width, ew, eh)) return fail(ctx, STK_INVALID_PARAMS, "scale_down_width gives an empty image");
     }
     const int cn = frames->channels;                    // 3 (BGR) or 4 (BGRA: the output is CV_32FC4 like the reference's)
@@ -544,16 +543,19 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     auto bail = [&](stk_status e) { (void)up.finish(nullptr); return e; };      // never leave the helper thread behind
     EccPlan pl{};
     if ((st = ecc_plan(ctx, ew, eh, n - 1, params->motion_type, pl))) return bail(st);
-    if (scaled) { hipError_t he = ctx->scratch.reserve((size_t)w * h + (size_t)ew * eh + 256); if (he != hipSuccess) return bail(fail(ctx, STK_HIP_ERROR, "scratch allocation failed")); }
+    // (scaled: the grey image and its INTER_AREA reduction keep the frames' depth, 8-bit or f32, as cvtColor and resize do)
+    const int gdepth = frames->depth;
+    const size_t gel = (size_t)gdepth / 8;
+    if (scaled) { hipError_t he = ctx->scratch.reserve(((size_t)w * h + (size_t)ew * eh) * gel + 512); if (he != hipSuccess) return bail(fail(ctx, STK_HIP_ERROR, "scratch allocation failed")); }
     uint8_t* gfull = ctx->scratch.as<uint8_t>();
-    uint8_t* gsmall = scaled ? gfull + (((size_t)w * h + 255) & ~(size_t)255) : nullptr;
+    uint8_t* gsmall = scaled ? gfull + (((size_t)w * h * gel + 255) & ~(size_t)255) : nullptr;
     // one moving frame's template on stream `s`: grey (-> scale_image) -> blur
     auto prepare_template = [&](int i, hipStream_t s) -> stk_status {
         float* t = ctx->templates.as<float>() + pl.templ_plane_stride * (size_t)(i - 1);
         if (!scaled) { HIP_TRY(launch_grey_blur(dev[i], frames->depth, cn, w, h, rb, params->gauss_filt_size, t, pl.templ_row_stride, s)); return STK_OK; }
-        HIP_TRY(launch_grey(dev[i], 8, w, h, rb, gfull, s, 1, 0, 0, cn));
-        HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, s));
-        HIP_TRY(launch_grey_blur(gsmall, 8, 1, ew, eh, (size_t)ew, params->gauss_filt_size, t, pl.templ_row_stride, s));
+        HIP_TRY(launch_grey(dev[i], gdepth, w, h, rb, gfull, s, 1, 0, 0, cn));
+        HIP_TRY(launch_resize_area(gfull, gdepth, w, h, gsmall, ew, eh, s));
+        HIP_TRY(launch_grey_blur(gsmall, gdepth, 1, ew, eh, (size_t)ew * gel, params->gauss_filt_size, t, pl.templ_row_stride, s));
         return STK_OK;
     };
     // templates of frames [first, first + count): one streaming launch for the whole run when the frames are evenly spaced
@@ -575,9 +577,9 @@ stk_status ecc_shard_impl(stk_ctx* ctx, const stk_frames* frames, const stk_ecc_
     };
     auto prepare_reference = [&](hipStream_t s) -> stk_status {
         if (!scaled) return ecc_prepare_reference(ctx, pl, dev[0], frames->depth, cn, rb, params->gauss_filt_size);
-        HIP_TRY(launch_grey(dev[0], 8, w, h, rb, gfull, s, 1, 0, 0, cn));
-        HIP_TRY(launch_resize_area_u8(gfull, w, h, gsmall, ew, eh, s));
-        return ecc_prepare_reference(ctx, pl, gsmall, 8, 1, (size_t)ew, params->gauss_filt_size);
+        HIP_TRY(launch_grey(dev[0], gdepth, w, h, rb, gfull, s, 1, 0, 0, cn));
+        HIP_TRY(launch_resize_area(gfull, gdepth, w, h, gsmall, ew, eh, s));
+        return ecc_prepare_reference(ctx, pl, gsmall, gdepth, 1, (size_t)ew * gel, params->gauss_filt_size);
     };
 
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));

@@ -264,6 +264,15 @@ def resize_area_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     return out
 
 
+def resize_area_f32(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    s = np.ascontiguousarray(src, np.float32)
+    out = np.empty((dh, dw), np.float32)
+    rc = lib().orc_resize_area_f32(_p(s), s.shape[1], s.shape[0], _p(out), dw, dh)
+    if rc:
+        raise ValueError("orc_resize_area_f32 rc=%d" % rc)
+    return out
+
+
 def sharpness(grey, metric: int, ksize: int = 0) -> float:
     """The reference's sharpness metrics (lib.rs:1030-1166): 0 LAPM, 1 LAPV, 2 TENG(ksize), 3 GLVN."""
     g = np.ascontiguousarray(grey)

@@ -18,6 +18,7 @@ int orc_warp_frame(const void* src, int depth, int w, int h, int cn, size_t stri
 int orc_scale(const float* in, size_t n, double divisor, float* out);
 int orc_scaled_size(int w, int h, float scale_down, int* nw, int* nh);
 int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
+int orc_resize_area_f32(const float* src, int sw, int sh, float* dst, int dw, int dh);
 }
 
 namespace {
@@ -364,7 +365,6 @@ int orc_ecc_match(const void* const* frames, int n, int w, int h, int depth, int
     if (scale_down > 0) {
         if (scale_down >= (float)w) return 2;           // InvalidParams lib.rs:876-881
         if (scale_down <= 10.0f) return 2;              // InvalidParams lib.rs:883-888
-        if (depth != 8) return 4;
         if (orc_scaled_size(w, h, scale_down, &ew, &eh)) return 2;
     }
     const size_t npx = (size_t)w * h, nel = npx * 3;
@@ -374,7 +374,13 @@ int orc_ecc_match(const void* const* frames, int n, int w, int h, int depth, int
     // findTransformECC accepts 8UC1 / 32FC1 only: 16-bit input fails in the reference.
     if (depth == 16) return 4;
     std::vector<uint8_t> small0;
-    if (scale_down > 0) { small0.resize((size_t)ew * eh); orc_resize_area_u8(grey0.data(), w, h, small0.data(), ew, eh); }
+    // (scale_image keeps the grey's depth: resize(INTER_AREA) on 8UC1 or 32FC1, utils.rs:186-214)
+    auto shrink = [&](const std::vector<uint8_t>& g, std::vector<uint8_t>& sm) {
+        sm.resize((size_t)ew * eh * gsz);
+        if (depth == 8) orc_resize_area_u8(g.data(), w, h, sm.data(), ew, eh);
+        else orc_resize_area_f32(reinterpret_cast<const float*>(g.data()), w, h, reinterpret_cast<float*>(sm.data()), ew, eh);
+    };
+    if (scale_down > 0) shrink(grey0, small0);
     orc_ecc_input* in = orc_ecc_prepare_input(scale_down > 0 ? small0.data() : grey0.data(), depth, ew, eh, gauss);
     if (!in) return 4;
 #ifdef _OPENMP
@@ -404,9 +410,9 @@ int orc_ecc_match(const void* const* frames, int n, int w, int h, int depth, int
             orc_grey(frames[i], depth, w, h, 0, grey.data());
             std::vector<float> tf((size_t)ew * eh);
             if (scale_down > 0) {
-                std::vector<uint8_t> sm((size_t)ew * eh);
-                orc_resize_area_u8(grey.data(), w, h, sm.data(), ew, eh);
-                orc_gaussian_blur_f32(sm.data(), 8, ew, eh, gauss, tf.data());
+                std::vector<uint8_t> sm;
+                shrink(grey, sm);
+                orc_gaussian_blur_f32(sm.data(), depth, ew, eh, gauss, tf.data());
             } else orc_gaussian_blur_f32(grey.data(), depth, w, h, gauss, tf.data());
             double rho;
             // inner loops are OpenMP-parallel too; nested regions stay serial by default

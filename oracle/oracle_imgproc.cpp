@@ -287,20 +287,48 @@ int area_tab(int ssize, int dsize, double scale, std::vector<DecimateAlpha>& tab
 }
 }  // namespace
 
-// resize(src, dsize, INTER_AREA) for an 8-bit single-channel image, shrinking in both directions.
-// Integer ratios take resizeAreaFast (sum * (1.f/area), cvRound); otherwise the fractional-coverage
-// tables, f32 accumulation in table order, rows combined as sum = beta0*buf0; sum += beta_k*buf_k.
-extern "C" int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+// resize(src, dsize, INTER_AREA) for a single-channel image, 8-bit or f32, shrinking in both directions [OCV-RECALL:
+// imgproc/src/resize.cpp]. Integer ratios take resizeAreaFast_: the 2 x 2 case is ResizeAreaFastVec's (a + b + c + d + 2) >> 2
+// for 8 bit (half rounds up) and the vector form ((a + b) + (c + d)) * 0.25f for f32 (its scalar tail of w mod the vector
+// width adds ((a + b) + c) + d: a last-bit difference on a few right-hand columns, not reproduced); other integer ratios sum
+// the cell (int for 8 bit; f32 in groups of four in row-major order for f32) and store saturate_cast<T>(sum * (1.f / area)).
+// Otherwise the fractional-coverage tables, f32 accumulation in table order, rows combined as sum = beta0*buf0;
+// sum += beta_k*buf_k.
+namespace {
+template <typename T> inline T area_store(float v);
+template <> inline uint8_t area_store<uint8_t>(float v) { return (uint8_t)std::min(std::max(cv_round(v), 0), 255); }
+template <> inline float area_store<float>(float v) { return v; }
+
+template <typename T>
+int resize_area_t(const T* src, int sw, int sh, T* dst, int dw, int dh) {
     if (dw <= 0 || dh <= 0 || dw > sw || dh > sh) return 3;
+    constexpr bool U8 = sizeof(T) == 1;
     const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
     const int isx = sat_int(scale_x), isy = sat_int(scale_y);
     if (std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON) {
         const float sc = 1.f / (isx * isy);
+        const int area = isx * isy;
         for (int y = 0; y < dh; y++)
             for (int x = 0; x < dw; x++) {
-                int sum = 0;
-                for (int j = 0; j < isy; j++) for (int i = 0; i < isx; i++) sum += src[(size_t)(y * isy + j) * sw + x * isx + i];
-                dst[(size_t)y * dw + x] = (uint8_t)std::min(std::max(cv_round((float)sum * sc), 0), 255);
+                const T* S = src + (size_t)(y * isy) * sw + (size_t)x * isx;
+                T& D = dst[(size_t)y * dw + x];
+                if (isx == 2 && isy == 2) {
+                    if (U8) D = (T)(((int)S[0] + (int)S[1] + (int)S[sw] + (int)S[sw + 1] + 2) >> 2);
+                    else D = (T)((((float)S[0] + (float)S[1]) + ((float)S[sw] + (float)S[sw + 1])) * 0.25f);
+                    continue;
+                }
+                if (U8) {
+                    int sum = 0;
+                    for (int k = 0; k < area; k++) sum += (int)S[(size_t)(k / isx) * sw + k % isx];
+                    D = area_store<T>((float)sum * sc);
+                } else {
+                    auto at = [&](int k) { return (float)S[(size_t)(k / isx) * sw + k % isx]; };
+                    float sum = 0.f;
+                    int k = 0;
+                    for (; k <= area - 4; k += 4) sum += ((at(k) + at(k + 1)) + at(k + 2)) + at(k + 3);
+                    for (; k < area; k++) sum += at(k);
+                    D = area_store<T>(sum * sc);
+                }
             }
         return 0;
     }
@@ -313,18 +341,26 @@ extern "C" int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* d
     for (size_t j = 0; j < yt.size(); j++) {
         const float beta = yt[j].alpha;
         const int dy = yt[j].di, sy = yt[j].si;
-        const uint8_t* S = src + (size_t)sy * sw;
+        const T* S = src + (size_t)sy * sw;
         std::fill(buf.begin(), buf.end(), 0.f);
-        for (const DecimateAlpha& t : xt) buf[t.di] += S[t.si] * t.alpha;
+        for (const DecimateAlpha& t : xt) buf[t.di] += (float)S[t.si] * t.alpha;
         if (dy != prev_dy) {
-            uint8_t* D = dst + (size_t)prev_dy * dw;
-            for (int dx = 0; dx < dw; dx++) { D[dx] = (uint8_t)std::min(std::max(cv_round(sum[dx]), 0), 255); sum[dx] = beta * buf[dx]; }
+            T* D = dst + (size_t)prev_dy * dw;
+            for (int dx = 0; dx < dw; dx++) { D[dx] = area_store<T>(sum[dx]); sum[dx] = beta * buf[dx]; }
             prev_dy = dy;
         } else {
             for (int dx = 0; dx < dw; dx++) sum[dx] += beta * buf[dx];
         }
     }
-    uint8_t* D = dst + (size_t)prev_dy * dw;
-    for (int dx = 0; dx < dw; dx++) D[dx] = (uint8_t)std::min(std::max(cv_round(sum[dx]), 0), 255);
+    T* D = dst + (size_t)prev_dy * dw;
+    for (int dx = 0; dx < dw; dx++) D[dx] = area_store<T>(sum[dx]);
     return 0;
+}
+}  // namespace
+
+extern "C" int orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+    return resize_area_t<uint8_t>(src, sw, sh, dst, dw, dh);
+}
+extern "C" int orc_resize_area_f32(const float* src, int sw, int sh, float* dst, int dw, int dh) {
+    return resize_area_t<float>(src, sw, sh, dst, dw, dh);
 }

@@ -412,3 +412,36 @@ def test_fast_score_map_matches_the_definition():
     got = oracle.fast_score_map(img, 20).astype(int)
     assert np.array_equal(got[3:h - 3, 3:w - 3], ref[3:h - 3, 3:w - 3])
     assert (ref > 0).sum() > 20
+
+
+def test_resize_area_known_answers_and_f32():
+    """scale_image's resize(INTER_AREA) (utils.rs:186-214). Exact halving is OpenCV's 2 x 2 special case: (a + b + c + d + 2) >> 2,
+    which rounds a half UP where cvRound (every other ratio) rounds it to even — pinned here by closed form (round 4: the oracle
+    and the kernel both used cvRound for it until now). The f32 form (a 32FC1 grey) against the plain area average."""
+    src = np.array([[1, 1, 2, 0, 255, 255, 3, 3],
+                    [0, 0, 0, 0, 255, 254, 2, 2]], np.uint8)
+    got = oracle.resize_area_u8(src, 4, 1)
+    assert got.tolist() == [[1, 1, 255, 3]]                  # sums 2, 2, 1019, 10: 0.5 -> 1 (cvRound would give 0), 254.75 -> 255, 2.5 -> 3 (cvRound: 2)
+    third = np.array([[1, 1, 0], [0, 0, 0], [0, 0, 0], [9, 9, 9], [9, 9, 9], [9, 9, 5]], np.uint8)
+    assert oracle.resize_area_u8(third, 1, 2).tolist() == [[0], [9]]        # 2 / 9 -> 0; 77 / 9 = 8.56 -> 9: cvRound(sum * (1.f / 9))
+    half_even = np.array([[1, 1, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], np.uint8)       # 4 / 16 ... use 4 x 4 -> 1 x 1: 0.25 -> 0
+    assert oracle.resize_area_u8(half_even, 1, 1).tolist() == [[0]]
+    eight = np.zeros((4, 4), np.uint8); eight[0] = 2                                                # 8 / 16 = 0.5 -> cvRound -> 0 (half to even)
+    assert oracle.resize_area_u8(eight, 1, 1).tolist() == [[0]]
+    rng = np.random.default_rng(11)
+    f = rng.random((48, 64), dtype=np.float32)
+    for dw, dh in ((32, 24), (16, 12), (21, 16), (64 // 3, 16), (50, 37)):
+        got = oracle.resize_area_f32(f, dw, dh)
+        sx, sy = 64 / dw, 48 / dh
+        ref = np.empty((dh, dw))
+        for y in range(dh):                                   # exact area integral of the piecewise-constant image
+            for x in range(dw):
+                x0, x1, y0, y1 = x * sx, min((x + 1) * sx, 64), y * sy, min((y + 1) * sy, 48)
+                xs = np.clip(np.minimum(np.arange(64) + 1, x1) - np.maximum(np.arange(64), x0), 0, None)
+                ys = np.clip(np.minimum(np.arange(48) + 1, y1) - np.maximum(np.arange(48), y0), 0, None)
+                ref[y, x] = ys @ f.astype(np.float64) @ xs / ((x1 - x0) * (y1 - y0))
+        assert np.abs(got - ref).max() < 2e-6, (dw, dh)
+    u = rng.integers(0, 256, (48, 64), dtype=np.uint8)        # the 8-bit form is the rounded f32 form except at exact halves
+    for dw, dh in ((16, 12), (21, 16), (50, 37)):
+        a, b = oracle.resize_area_u8(u, dw, dh).astype(int), oracle.resize_area_f32(u.astype(np.float32), dw, dh)
+        assert np.abs(a - b).max() <= 0.5 + 1e-4

@@ -346,9 +346,20 @@ def test_ecc_match_f32_frames(stacker, small_stack):
         assert synth.corner_error(stats[i]["warp"], warps[i], 320, 240) <= 0.05
         assert stats[i]["iterations"] == int(iters[i])
     assert_ecc_stack_close(out, ref, f32, warps, label="f32 frames", iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
+    # ecc_match_scaling_down on the same float stack (round 4): the 32FC1 grey is shrunk as it is (lib.rs:896, 921); 120 halves the
+    # 320 x 240 frames exactly (2 x 2 cells), 100 -> fractional coverage
+    for sd in (120.0, 100.0):
+        out, stats = stacker.ecc_match(f32, PARAMS, scale_down_width=sd, return_stats=True)
+        ref, warps, iters = oracle.ecc_match(f32, max_count=5000, epsilon=1e-5, gauss_filt_size=5, scale_down_width=sd)
+        for i in (1, 2):
+            assert synth.corner_error(stats[i]["warp"], warps[i], 320, 240) <= 0.1
+            assert stats[i]["iterations"] == int(iters[i])
+        assert_ecc_stack_close(out, ref, f32, warps, label="f32 frames, scale_down %g" % sd, iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
     # 16-bit frames: the reference's grey is 16UC1, which findTransformECC rejects -> OpenCvError
     with pytest.raises(OpenCvError):
         stacker.ecc_match([f.astype(np.uint16) for f in frames[:2]], PARAMS)
+    with pytest.raises(OpenCvError):
+        stacker.ecc_match([f.astype(np.uint16) for f in frames[:2]], PARAMS, scale_down_width=120.0)
 
 
 @pytest.mark.parametrize("depth,gauss", [(8, 3), (8, 5), (8, 7), (16, 5)])

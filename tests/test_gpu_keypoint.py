@@ -190,6 +190,18 @@ def test_scale_image_inter_area_bit_exact(stacker):
     tall = rng.integers(0, 256, (300, 120), dtype=np.uint8)   # width < height: the WIDTH becomes scale_down
     got = stacker.scale_image_grey(tall, 60.0)
     assert got.shape == (150, 60) and np.array_equal(got, oracle.resize_area_u8(tall, 60, 150))
+    # exact halving rounds a half UP ((a + b + c + d + 2) >> 2), the other ratios to even (cvRound): closed form
+    two = np.zeros((16, 16), np.uint8); two[0::2, 0::2] = 2                 # every 2 x 2 cell sums to 2: 0.5
+    assert (stacker.scale_image_grey(two, 8.0) == 1).all()
+    quarter = np.zeros((32, 32), np.uint8); quarter[0::4, 0::4] = 8         # every 4 x 4 cell sums to 8: 0.5 -> 0
+    assert (stacker.scale_image_grey(quarter, 8.0) == 0).all()
+    # a 32FC1 grey (float stacks; round 4): the same tables without the rounding, bit for bit against the oracle
+    f = rng.random((480, 640), dtype=np.float32) * 255
+    for sd in (200.0, 240.0, 160.0, 333.0, 97.5):              # 240 -> 2 x 2 (vector form), 160 -> 3 x 3 (groups of four), others fractional
+        nw, nh = oracle.scaled_size(640, 480, sd)
+        got = stacker.scale_image_grey(f, sd)
+        assert got.dtype == np.float32 and got.shape == (nh, nw)
+        assert np.array_equal(got, oracle.resize_area_f32(f, nw, nh)), sd
 
 
 def test_keypoint_match_scale_down_matches_oracle(stacker, kp_stack):
