@@ -1,160 +1,22 @@
-// kernels_orb.hip — ORB::detect_and_compute (utils.rs:174-183) and the
-// brute-force Hamming 2-NN matcher (lib.rs:208-219; row C1) as gfx950 kernels. All integer / byte
-// work on 8-bit pyramids: HBM/L2-bound stencils, no MFMA.
+// kernels_orb.hip — ORB::detect_and_compute (utils.rs:174-183), scale_image's resize(INTER_AREA)
+// (utils.rs:186-214) and the brute-force Hamming 2-NN matcher (lib.rs:208-219; row C1) as gfx950 kernels: the production
+// path. All integer / byte work on 8-bit pyramids, integer-VALU-bound, no MFMA.
 //
-//   resize_exact   INTER_LINEAR_EXACT 8-bit downscale (8.8 fixed-point coefficients, (v + 2^15) >> 16)
-//   fast_score     FAST-9/16 corner strength per pixel (0 = not a corner at the threshold)
-//   fast_nms       3x3 strict non-maximum suppression + runByImageBorder(31) + score histogram + collect
-//   fast_threshold per level: the score of the (2 n_l)-th best corner (retainBest keeps ties)
-//   fast_pick / fast_describe   candidates >= threshold -> short list; Harris response and IC moments, a wave per corner
-//   gauss7_rows/cols  GaussianBlur 7x7 sigma 2 (float separable filter, cvRound to u8)
-//   brief          rotated BRIEF, 256 tests, one lane per descriptor byte
-//   knn2_hamming   popcount(xor) over 32 B, two best train rows per query, ties keep the lower index
-#include "common.h"
-#include "keypoint.h"
+//   resize_tables / resize_exact_direct   INTER_LINEAR_EXACT pyramid step from per-geometry tables, no LDS, 4 x 4 pixels per thread
+//   resize_area                           INTER_AREA (8-bit and f32 greys), OpenCV's table order
+//   fast_nms_tiled(_all)                  FAST-9/16 pre-test + strength + 3x3 NMS + border + histogram + collect, 128 x 32 tiles of ALL levels in one launch
+//   fast_threshold / fast_pick / fast_describe / orb_cull   retainBest threshold, short list, Harris + IC moments (a wave per corner), device cull
+//   gauss7_fused                          7x7 sigma-2 blur of a whole level (only behind orb_patch_blur = 0)
+//   brief_patch / brief                   blur of the sampled window + rotated BRIEF / rBRIEF on a blurred level
+//   knn2_hamming                          popcount(xor) over 32 B, two best train rows per query, ties keep the lower index
+// The plain per-pixel forms the tiled kernels replaced (and fall back to for tiny or unaligned levels) live in
+// kernels_orb_small.hip; the device helpers both files use in orb_device.h.
+#include "orb_device.h"
 
 namespace stk {
 
-// ---- shared helpers ---------------------------------------------------------------------------------
-__device__ __forceinline__ int refl101(int p, int len) {
-    if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
-
-// four bytes at any address through aligned dword loads (level rows are not dword-aligned in general)
-__device__ __forceinline__ uint32_t load4_unaligned(const uint8_t* p) {
-    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh);   // pointer arithmetic keeps the address space: global_load, not flat_load
-    const uint32_t lo = q[0];
-    if (sh == 0) return lo;
-    return __builtin_amdgcn_alignbyte(q[1], lo, sh);   // bytes sh .. sh+3 of the aligned pair
-}
-
 // ---- pyramid ------------------------------------------------------------------------------------
-__device__ __forceinline__ void lin_coef(int d, int src, double scale, int& ofs, int& c0, int& c1) {
-    const double fval = scale * ((double)d + 0.5) - 0.5;
-    const int ival = (int)floor(fval);
-    if (ival >= 0 && src > 1) {
-        if (ival < src - 1) { ofs = ival; c1 = (int)__builtin_rint((fval - (double)ival) * 256.0); c0 = 256 - c1; }
-        else { ofs = src - 1; c0 = 256; c1 = 0; }
-    } else { ofs = 0; c0 = 256; c1 = 0; }
-}
-
-__global__ __launch_bounds__(256) void resize_exact_kernel(const uint8_t* __restrict__ src, int sw, int sh,
-                                                           uint8_t* __restrict__ dst, int dw, int dh,
-                                                           double scale_x, double scale_y, size_t frame_stride) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
-    src += blockIdx.z * frame_stride; dst += blockIdx.z * frame_stride;      // batched over frames
-    int ox, cx0, cx1, oy, cy0, cy1;
-    lin_coef(x, sw, scale_x, ox, cx0, cx1);
-    lin_coef(y, sh, scale_y, oy, cy0, cy1);
-    const int ox1 = min(ox + 1, sw - 1), oy1 = min(oy + 1, sh - 1);
-    const uint8_t* r0 = src + (size_t)oy * sw;
-    const uint8_t* r1 = src + (size_t)oy1 * sw;
-    const uint32_t h0 = (uint32_t)cx0 * r0[ox] + (uint32_t)cx1 * r0[ox1];
-    const uint32_t h1 = (uint32_t)cx0 * r1[ox] + (uint32_t)cx1 * r1[ox1];
-    const uint32_t v = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1;
-    dst[(size_t)y * dw + x] = (uint8_t)min((v + (1u << 15)) >> 16, 255u);
-}
-
-// Tiled pyramid step: a 128 x 32 output tile per workgroup. The 8.8 coefficients of the tile's 128 columns and 32 rows
-// are computed once (in double, as above) into LDS, the source footprint of the tile goes to LDS through aligned dword
-// loads, and every output is two table reads + four LDS byte reads. Same arithmetic, bit-identical.
-constexpr int RT_X = 128, RT_Y = 32;
-constexpr int RT_SW = 176, RT_SH = 48;               // source footprint capacity (scale <= 1.3 plus the +1 tap)
-
-__global__ __launch_bounds__(256) void resize_exact_tiled_kernel(const uint8_t* __restrict__ src, int sw, int sh,
-                                                                 uint8_t* __restrict__ dst, int dw, int dh,
-                                                                 double scale_x, double scale_y, size_t frame_stride) {
-    __shared__ __attribute__((aligned(16))) uint8_t T[RT_SH * RT_SW];
-    __shared__ int xo[RT_X], xc[RT_X], yo[RT_Y], yc[RT_Y];
-    src += blockIdx.z * frame_stride; dst += blockIdx.z * frame_stride;
-    const int x0 = blockIdx.x * RT_X, y0 = blockIdx.y * RT_Y;
-    const int tid = threadIdx.x;
-    if (tid < RT_X) {
-        int o, c0, c1;
-        lin_coef(min(x0 + tid, dw - 1), sw, scale_x, o, c0, c1);
-        xo[tid] = o; xc[tid] = c1;
-    } else if (tid < RT_X + RT_Y) {
-        int o, c0, c1;
-        lin_coef(min(y0 + tid - RT_X, dh - 1), sh, scale_y, o, c0, c1);
-        yo[tid - RT_X] = o; yc[tid - RT_X] = c1;
-    }
-    __syncthreads();
-    const int sx_lo = xo[0] & ~3, sy_lo = yo[0];
-    const int nx = min(dw - x0, RT_X), ny = min(dh - y0, RT_Y);
-    const int sx_hi = min(xo[nx - 1] + 1, sw - 1), sy_hi = min(yo[ny - 1] + 1, sh - 1);
-    const int tw4 = (sx_hi - sx_lo) / 4 + 1, th = sy_hi - sy_lo + 1;          // dwords per row, rows
-    if (tw4 * 4 > RT_SW || th > RT_SH) {                                          // never for pyramid steps; keep it correct anyway
-        for (int i = tid; i < nx * ny; i += 256) {
-            const int tx = i % nx, ty = i / nx;
-            const int ox = xo[tx], cx1 = xc[tx], cx0 = 256 - cx1, oy = yo[ty], cy1 = yc[ty], cy0 = 256 - cy1;
-            const int ox1 = min(ox + 1, sw - 1), oy1 = min(oy + 1, sh - 1);
-            const uint8_t* r0 = src + (size_t)oy * sw;
-            const uint8_t* r1 = src + (size_t)oy1 * sw;
-            const uint32_t h0 = (uint32_t)cx0 * r0[ox] + (uint32_t)cx1 * r0[ox1], h1 = (uint32_t)cx0 * r1[ox] + (uint32_t)cx1 * r1[ox1];
-            const uint32_t v = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1;
-            dst[(size_t)(y0 + ty) * dw + x0 + tx] = (uint8_t)min((v + (1u << 15)) >> 16, 255u);
-        }
-        return;
-    }
-    for (int i = tid; i < th * tw4; i += 256) {
-        const int ty = i / tw4, d = i - ty * tw4;
-        const int gx = sx_lo + 4 * d;
-        const uint8_t* row = src + (size_t)(sy_lo + ty) * sw;
-        uint32_t v = 0;
-        if (gx + 3 < sw) v = load4_unaligned(row + gx);
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) v |= (uint32_t)row[min(gx + e, sw - 1)] << (8 * e);
-        }
-        *reinterpret_cast<uint32_t*>(T + ty * RT_SW + 4 * d) = v;
-    }
-    __syncthreads();
-    // thread = 4 adjacent columns x 4 rows (rows tid/32 + 8k); the columns' offsets and weights are read and prepared once
-    // for the four rows (round 3: they were re-read from LDS for every output)
-    const int q = tid & 31, rg = tid >> 5;
-    const bool aligned = (dw & 3) == 0;
-    int cx[4], o0[4], o1[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int tx = 4 * q + e;
-        const int ox = xo[tx];
-        cx[e] = xc[tx]; o0[e] = ox - sx_lo; o1[e] = min(ox + 1, sw - 1) - sx_lo;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int ty = rg + 8 * k;
-        const int y = y0 + ty;
-        if (y >= dh) continue;
-        const int oy = yo[ty], cy1 = yc[ty], cy0 = 256 - cy1;
-        const uint8_t* r0 = T + (oy - sy_lo) * RT_SW;
-        const uint8_t* r1 = T + (min(oy + 1, sh - 1) - sy_lo) * RT_SW;
-        uint32_t out = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int cx1 = cx[e], cx0 = 256 - cx1;
-            const uint32_t h0 = (uint32_t)cx0 * r0[o0[e]] + (uint32_t)cx1 * r0[o1[e]];
-            const uint32_t h1 = (uint32_t)cx0 * r1[o0[e]] + (uint32_t)cx1 * r1[o1[e]];
-            const uint32_t v = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1;
-            out |= min((v + (1u << 15)) >> 16, 255u) << (8 * e);
-        }
-        const int x = x0 + 4 * q;
-        if (x >= dw) continue;
-        uint8_t* op = dst + (size_t)y * dw + x;
-        if (aligned && x + 3 < dw) *reinterpret_cast<uint32_t*>(op) = out;
-        else {
-            op[0] = (uint8_t)out;
-            if (x + 1 < dw) op[1] = (uint8_t)(out >> 8);
-            if (x + 2 < dw) op[2] = (uint8_t)(out >> 16);
-            if (x + 3 < dw) op[3] = (uint8_t)(out >> 24);
-        }
-    }
-}
-
-// Round 3: the pyramid step without a tile. The tiled kernel above is neither VALU- nor HBM-bound (SQ counters: 6 waves per
+// Round 3: the pyramid step without a tile. The tiled kernel (kernels_orb_small.hip) is neither VALU- nor HBM-bound (SQ counters: 6 waves per
 // SIMD that each live 7 us): table computation in f64 by 160 threads while the others wait, a staged footprint behind a
 // barrier, four LDS byte reads per pixel. A first rewrite that kept the tile but read its tables from memory cut the VALU
 // count by 40 % and the time by nothing. This one has no LDS and no barrier: a thread makes 4 adjacent pixels of 4 rows; the
@@ -247,15 +109,7 @@ hipError_t launch_resize_exact(const uint8_t* src, int sw, int sh, uint8_t* dst,
             return hipGetLastError();
         }
     }
-    const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
-    if (sw >= 8 && sh >= 2 && sx <= 1.3 && sy <= 1.3 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (frame_stride & 3) == 0) {
-        dim3 tgrid((dw + RT_X - 1) / RT_X, (dh + RT_Y - 1) / RT_Y, n_frames);
-        resize_exact_tiled_kernel<<<tgrid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, sx, sy, frame_stride);
-        return hipGetLastError();
-    }
-    dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_frames);
-    resize_exact_kernel<<<grid, 256, 0, s>>>(src, sw, sh, dst, dw, dh, sx, sy, frame_stride);
-    return hipGetLastError();
+    return launch_resize_exact_plain(src, sw, sh, dst, dw, dh, s, n_frames, frame_stride);
 }
 
 // ---- scale_image: resize(INTER_AREA) of a grey image, 8-bit or f32 (utils.rs:186-214) -------------------
@@ -354,52 +208,6 @@ hipError_t launch_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* ds
 }
 
 // ---- FAST -----------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_ring(const uint8_t* __restrict__ p, int stride, int v, int (&d)[16]) {
-    d[0] = v - p[3 * stride];        d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];   d[3] = v - p[stride + 3];
-    d[4] = v - p[3];                 d[5] = v - p[-stride + 3];      d[6] = v - p[-2 * stride + 2];  d[7] = v - p[-3 * stride + 1];
-    d[8] = v - p[-3 * stride];       d[9] = v - p[-3 * stride - 1];  d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
-    d[12] = v - p[-3];               d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];  d[15] = v - p[3 * stride - 1];
-}
-
-// corner strength: the largest t for which the pixel is still a FAST-9 corner at threshold t (0 if none above thr)
-__device__ __forceinline__ int fast_strength(const int (&d)[16], int thr) {
-    int best = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int mn = d[k], mx = d[k];
-#pragma unroll
-        for (int j = 1; j < 9; j++) { mn = min(mn, d[(k + j) & 15]); mx = max(mx, d[(k + j) & 15]); }
-        best = max(best, max(mn, -mx));
-    }
-    return best > thr ? best - 1 : 0;
-}
-
-__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int stride, int thr) {
-    const int v = p[0];
-    // high-speed rejection: any 9 contiguous ring pixels contain at least two of the four compass points
-    const int n0 = v - p[3 * stride], n4 = v - p[3], n8 = v - p[-3 * stride], n12 = v - p[-3];
-    const int dark = (n0 > thr) + (n4 > thr) + (n8 > thr) + (n12 > thr);
-    const int bright = (n0 < -thr) + (n4 < -thr) + (n8 < -thr) + (n12 < -thr);
-    if (dark < 2 && bright < 2) return 0;
-    int d[16];
-    fast_ring(p, stride, v, d);
-    return fast_strength(d, thr);
-}
-
-// Batched over frames: blockIdx.z (or the named grid dimension) is the frame; per-frame arrays sit `*_stride`
-// elements apart (OrbBatch). n_frames = 1 and zero strides give the single-image form.
-struct OrbBatch { size_t pyr, states, cand, sel; };
-
-__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h, int thr,
-                                                         uint8_t* __restrict__ score, OrbBatch bs) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    img += blockIdx.z * bs.pyr; score += blockIdx.z * bs.pyr;
-    int s = 0;
-    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) s = fast_score_at(img + (size_t)y * w + x, w, thr);
-    score[(size_t)y * w + x] = (uint8_t)s;
-}
-
 // Tiled FAST + non-maximum suppression: a 128 x 32 pixel tile in LDS (4 px halo: 1 for the 3x3 NMS neighbourhood
 // + 3 for the ring) and three scoring passes with workgroup-level compaction, so that the expensive steps run on densely
 // populated wavefronts instead of on every wavefront that contains one candidate:
@@ -697,20 +505,6 @@ __global__ __launch_bounds__(256) void fast_nms_tiled_all_kernel(const uint8_t* 
     fast_nms_tiled_body(pyr + L.pyr_ofs[l], L.w[l], L.h[l], thr, edge, st + l, cand + L.cand_ofs[l], L.cand_cap[l], bs, tx, ty);
 }
 
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, int w, int h, int edge,
-                                                       OrbLevelState* st, OrbCandidate* cand, int cap, OrbBatch bs) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63) + edge, y = blockIdx.y * 4 + (threadIdx.x >> 6) + edge;
-    if (x >= w - edge || y >= h - edge) return;
-    score += blockIdx.z * bs.pyr; st += blockIdx.z * bs.states; cand += blockIdx.z * bs.cand;
-    const uint8_t* c = score + (size_t)y * w + x;
-    const int s = c[0];
-    if (!s) return;
-    if (s > c[-1] && s > c[1] && s > c[-w - 1] && s > c[-w] && s > c[-w + 1] && s > c[w - 1] && s > c[w] && s > c[w + 1]) {
-        atomicAdd(&st->hist[s], 1);
-        const int i = atomicAdd(&st->n_cand, 1);
-        if (i < cap) { cand[i].xy = x | (y << 16); cand[i].score = s; }
-    }
-}
 
 // retainBest(2 n_l) by FAST score: the largest score s whose "count of candidates >= s" reaches `keep`. One wavefront per
 // (frame, level): lane L owns bins 4 L .. 4 L + 3, an inclusive suffix sum over the lanes gives every bin its count from
@@ -928,12 +722,8 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
             fast_nms_tiled_kernel<<<tgrid, 256, 0, s>>>(img, w, h, thr, edge, st, cand, cap, bs);
         }
     } else {
-        dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
-        fast_score_kernel<<<grid, 256, 0, s>>>(img, w, h, thr, score, bs);
-        if (w > 2 * edge && h > 2 * edge) {
-            dim3 g2((w - 2 * edge + 63) / 64, (h - 2 * edge + 3) / 4, n_frames);
-            fast_nms_kernel<<<g2, 256, 0, s>>>(score, w, h, edge, st, cand, cap, bs);
-        }
+        const hipError_t e = launch_fast_score_nms_plain(img, w, h, thr, edge, score, st, cand, cap, s, n_frames, bs);
+        if (e != hipSuccess) return e;
     }
     fast_threshold_kernel<<<n_frames, 64, 0, s>>>(st, keep, bs);
     fast_pick_kernel<<<dim3(std::min((cap + 63) / 64, 64), n_frames), 64, 0, s>>>(st, cand, cap, sel, sel_cap, bs);
@@ -941,36 +731,12 @@ hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge
     return hipGetLastError();
 }
 
-// ---- 7x7 Gaussian on 8-bit levels -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gauss7_rows_kernel(const uint8_t* __restrict__ src, int w, int h, Gauss7 k,
-                                                          float* __restrict__ tmp, size_t pyr_stride, size_t tmp_stride) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    src += blockIdx.z * pyr_stride; tmp += blockIdx.z * tmp_stride;
-    const uint8_t* s = src + (size_t)y * w;
-    float acc = k.k[0] * (float)s[refl101(x - 3, w)];
-#pragma unroll
-    for (int i = 1; i < 7; i++) acc += k.k[i] * (float)s[refl101(x - 3 + i, w)];
-    tmp[(size_t)y * w + x] = acc;
-}
 
-__global__ __launch_bounds__(256) void gauss7_cols_kernel(const float* __restrict__ tmp, int w, int h, Gauss7 k,
-                                                          uint8_t* __restrict__ dst, size_t pyr_stride, size_t tmp_stride) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    tmp += blockIdx.z * tmp_stride; dst += blockIdx.z * pyr_stride;
-    float acc = k.k[3] * tmp[(size_t)y * w + x];
-#pragma unroll
-    for (int i = 1; i <= 3; i++)
-        acc += k.k[3 + i] * (tmp[(size_t)refl101(y - i, h) * w + x] + tmp[(size_t)refl101(y + i, h) * w + x]);
-    const int r = (int)__builtin_rintf(acc);
-    dst[(size_t)y * w + x] = (uint8_t)min(max(r, 0), 255);
-}
 
 // Fused 7x7 blur: a 128 x 32 output tile per workgroup. The 8-bit source tile with its halo goes to LDS through
 // aligned dword loads (level rows are not dword-aligned in general: two aligned dwords + v_alignbyte give the four
 // bytes at any offset), the row pass writes an f32 tile to LDS, the column pass rounds to 8 bits. Same operation
-// order as the two-kernel form above (kept for images narrower than the halo), so the result is bit-identical.
+// order as the two-kernel form (kernels_orb_small.hip, kept for images narrower than the halo), so the result is bit-identical.
 constexpr int G7_X = 128, G7_Y = 32, G7_HX = 4, G7_R = 3;
 typedef float g7f2 __attribute__((ext_vector_type(2)));
 constexpr int G7_TW = G7_X + 2 * G7_HX;              // 136 bytes per tile row
@@ -1076,10 +842,7 @@ hipError_t launch_gauss7(const uint8_t* src, int w, int h, const Gauss7& k, floa
         gauss7_fused_kernel<<<fgrid, 256, 0, s>>>(src, w, h, k, dst, pyr_stride);
         return hipGetLastError();
     }
-    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
-    gauss7_rows_kernel<<<grid, 256, 0, s>>>(src, w, h, k, tmp, pyr_stride, tmp_stride);
-    gauss7_cols_kernel<<<grid, 256, 0, s>>>(tmp, w, h, k, dst, pyr_stride, tmp_stride);
-    return hipGetLastError();
+    return launch_gauss7_plain(src, w, h, k, tmp, dst, s, n_frames, pyr_stride, tmp_stride);
 }
 
 // ---- rotated BRIEF ------------------------------------------------------------------------------------

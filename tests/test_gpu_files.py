@@ -43,7 +43,7 @@ def test_imread_pnm_variants(stacker, tmp_path):
     with pytest.raises(OpenCvError):
         stacker.imread(tmp_path / "photo.jpg")                     # missing file: empty Mat -> cvtColor raises
     with pytest.raises(NotImplementedYet):
-        stacker.imread(tmp_path / "photo.webp")                    # no codec in this build
+        stacker.imread(tmp_path / "photo.exr")                     # no codec in this build
 
 
 def test_path_based_entry_points_equal_frame_based(stacker, tmp_path):

@@ -8,7 +8,7 @@ calibration rows are in the same run: `scale_kernel` (float4 stream, 4 B read pe
 8-byte gathers: ~3 B/px/frame). `_calibration` lists raw FETCH_SIZE / known bytes for each.
 `_kernel_source_sha256` pins the summary to the sources it was measured with — argv[2] = ecc (default: the ECC kernels AND
 the host schedule, slots per launch and workgroups per frame: kernels_ecc_col.hip, kernels_ecc_solve.hip, ecc_solve_body.h,
-kernels_ecc.hip, stacker.cpp), keypoint (kernels_orb.hip, keypoint.cpp, kernels_warp.hip, kernels_homography.hip) or hybrid (both
+kernels_ecc.hip, stacker.cpp), keypoint (kernels_orb.hip, orb_device.h, kernels_orb_small.hip, keypoint.cpp, kernels_warp.hip, kernels_homography.hip) or hybrid (both
 sets) — concatenated (bench.py ignores a stale one).
 Round 4 adds, per kernel: SQ_INSTS_SALU / LDS / BRANCH / SMEM, the clock held (GRBM_GUI_ACTIVE / 8 / mean duration) and, for the
 ECC pass, `_issue_slots_per_px`: the STATIC cost of the ring loop's row in issue slots (tools/isa_loops.py on the kernel's ISA,
@@ -65,7 +65,7 @@ for k, v in res.items():
 out = dict(res)
 # pins the summary to the sources it was measured with
 ECC = ['kernels_ecc_col.hip', 'kernels_ecc_solve.hip', 'ecc_solve_body.h', 'kernels_ecc.hip', 'stacker.cpp']
-KP = ['kernels_orb.hip', 'keypoint.cpp', 'kernels_warp.hip', 'kernels_homography.hip']
+KP = ['kernels_orb.hip', 'orb_device.h', 'kernels_orb_small.hip', 'keypoint.cpp', 'kernels_warp.hip', 'kernels_homography.hip']
 pin = sys.argv[2] if len(sys.argv) > 2 else 'ecc'
 files = {'ecc': ECC, 'keypoint': KP, 'hybrid': ECC + KP}[pin]
 h = hashlib.sha256()
