@@ -282,7 +282,7 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
                                   int32_t* n_added, stk_frame_stats* stats);
 
 /* ---- file front-end ---------------------------------------------------------
- * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit), grey / YCbCr
+ * imgcodecs::imread(path, IMREAD_UNCHANGED) (utils.rs:110-117, 132) for binary PNM (P5 / P6, 8 or 16 bit), grey / YCbCr / CMYK
  * JPEG (libjpeg-turbo's libjpeg.so.8, OpenCV's decoder family at its default settings), PNG (libpng16.so.16: 8- and 16-bit
  * grey / RGB, palette -> BGR, 1/2/4-bit grey -> 8 bit; anything with alpha — RGBA, grey + alpha, a tRNS chunk — comes out as
  * FOUR channels B G R A, as OpenCV's decoder delivers it under IMREAD_UNCHANGED) and stripped 8/16-bit grey / RGB TIFF
@@ -290,7 +290,8 @@ stk_status stk_hybrid_match_shard(stk_ctx* ctx, const stk_frames* frames, const 
  * data == NULL only reports the geometry. ctx may be NULL. A file that is unreadable or not an image: STK_BACKEND_ERROR (the
  * reference's empty Mat + cvtColor). TIFF may be stripped or tiled, RGBA TIFF gives four channels; BMP (no library:
  * uncompressed 24-bit, 32-bit -> B G R A, 8-bit palette -> BGR or grey); still WebP (libwebp.so.7: BGR, or B G R A when the
- * bitstream has alpha). Flavours no decoder here takes (CMYK JPEG, planar TIFF, RLE / 1- / 4- / 16-bit BMP, animated WebP,
+ * bitstream has alpha). CMYK / YCCK JPEG comes out as B G R through
+ * OpenCV's own conversion. Flavours no decoder here takes (planar TIFF, RLE / 1- / 4- / 16-bit BMP, animated WebP,
  * EXR / JPEG 2000 ...): STK_NOT_IMPLEMENTED — the caller decodes those itself and uses the frame-based entry points. */
 stk_status stk_imread(stk_ctx* ctx, const char* path, void* data, size_t capacity_bytes, int32_t* width,
                       int32_t* height, int32_t* channels, int32_t* depth);

@@ -6,7 +6,8 @@
 // grey / RGB TIFF (libtiff's handle API) through libpng16.so.16 / libjpeg.so.8 / libtiff.so.5 loaded at run time — the image
 // has the libraries but not their headers, so the entry points used are declared below. Round 4: PNG with alpha or tRNS and
 // RGBA TIFF decode to four channels as the reference's imread does, tiled TIFF, uncompressed BMP, still WebP (libwebp.so.7).
-// What the build does not take (separate-plane TIFF; CMYK JPEG; animated WebP; EXR / JPEG 2000) returns
+// CMYK / YCCK JPEG comes out as B G R through OpenCV's own conversion. What the build does not take (separate-plane TIFF;
+// animated WebP; EXR / JPEG 2000) returns
 // STK_NOT_IMPLEMENTED and the caller decodes it itself (the frame-based entry points are the boundary). A file that is
 // missing or not an image behaves as in the reference: imread gives an empty Mat and the following cvtColor raises ->
 // STK_BACKEND_ERROR (OpenCvError).
@@ -551,7 +552,7 @@ bool jpeg_sof(const unsigned char* b, size_t n, unsigned& w, unsigned& h, int& c
 // The libjpeg calls proper. longjmp lands back in this frame, so it owns nothing with a destructor and changes no
 // automatic object after setjmp except through `volatile` PODs and caller-provided raw buffers (ISO C++ [support.runtime]:
 // anything else would be indeterminate after the jump): `store` holds the decompress object (capacity >= 4096 + 256),
-// `pix` the sw * shh * scomp output bytes, `line` one row. 0 decoded; 1 not decodable; 2 not taken by this build.
+// `pix` the sw * shh * (1 or 3) output bytes, `line` one decoded row (scomp samples per pixel). 0 decoded; 1 not decodable; 2 not taken by this build.
 static int jpeg_decode_raw(const JpegApi& api, const unsigned char* file, size_t file_size, unsigned sw, unsigned shh, int scomp,
                            unsigned char* store, size_t store_cap, unsigned char* pix, unsigned char* line, int* struct_size_io) noexcept {
     JpegErrorMgr err;
@@ -586,10 +587,13 @@ static int jpeg_decode_raw(const JpegApi& api, const unsigned char* file, size_t
     if (api.read_header(c, 1) != 1) { api.destroy(c); return 1; }
     // the declared layout must agree with the file: otherwise hands off
     if (c->image_width != sw || c->image_height != shh || c->num_components != scomp) { api.destroy(c); return 2; }
-    c->out_color_space = scomp == 3 ? 2 : 1;                // JCS_RGB / JCS_GRAYSCALE (library defaults otherwise)
+    // JCS_GRAYSCALE / JCS_RGB / JCS_CMYK (library defaults otherwise). Four components (CMYK, or YCCK which the library turns
+    // into CMYK): OpenCV's JpegDecoder asks for JCS_CMYK and converts to three channels itself [OCV-RECALL: grfmt_jpeg.cpp,
+    // icvCvt_CMYK2BGR_8u_C4C3R] — the file's samples are Adobe's inverted CMYK: c' = k - ((255 - c) * k >> 8), B G R = y' m' c'.
+    c->out_color_space = scomp == 4 ? 4 : scomp == 3 ? 2 : 1;
     api.start(c);
     if (c->output_width != sw || c->output_height != shh || c->output_components != scomp || c->output_scanline != 0) { api.destroy(c); return 2; }
-    const size_t row = (size_t)sw * scomp;
+    const size_t row = (size_t)sw * (scomp == 1 ? 1 : 3);
     for (volatile unsigned y = 0; y < shh; y = y + 1) {
         unsigned char* lp = line;
         const unsigned got = api.read_scanlines(c, &lp, 1);
@@ -597,29 +601,36 @@ static int jpeg_decode_raw(const JpegApi& api, const unsigned char* file, size_t
         if (got != 1 || at != y + 1) { api.destroy(c); return at != y + 1 ? 2 : 1; }
         unsigned char* o = pix + row * y;
         if (scomp == 1) std::memcpy(o, lp, row);
-        else for (unsigned x = 0; x < sw; x++) { o[3 * x] = lp[3 * x + 2]; o[3 * x + 1] = lp[3 * x + 1]; o[3 * x + 2] = lp[3 * x]; }   // RGB -> BGR
+        else if (scomp == 3) for (unsigned x = 0; x < sw; x++) { o[3 * x] = lp[3 * x + 2]; o[3 * x + 1] = lp[3 * x + 1]; o[3 * x + 2] = lp[3 * x]; }   // RGB -> BGR
+        else for (unsigned x = 0; x < sw; x++) {
+            const int k = lp[4 * x + 3];
+            o[3 * x + 2] = (unsigned char)(k - (((255 - lp[4 * x]) * k) >> 8));
+            o[3 * x + 1] = (unsigned char)(k - (((255 - lp[4 * x + 1]) * k) >> 8));
+            o[3 * x] = (unsigned char)(k - (((255 - lp[4 * x + 2]) * k) >> 8));
+        }
     }
     api.finish(c);
     api.destroy(c);
     return 0;
 }
 
-// 0 decoded (BGR or grey, 8 bit); 1 not decodable; 2 a flavour / library this build does not take
+// 0 decoded (BGR or grey, 8 bit; CMYK / YCCK files as BGR); 1 not decodable; 2 a flavour / library this build does not take
 int jpeg_load(const std::vector<unsigned char>& file, Pnm& p, std::vector<unsigned char>& pix) {
     const JpegApi& api = jpeg_api();
     if (!api.ok) return 2;
     unsigned sw = 0, shh = 0; int scomp = 0;
     if (!jpeg_sof(file.data(), file.size(), sw, shh, scomp)) return 1;
     if (sw == 0 || shh == 0 || sw > 65500 || shh > 65500) return 1;
-    if (scomp != 1 && scomp != 3) return 2;                                 // CMYK / YCCK: left to the caller
+    if (scomp != 1 && scomp != 3 && scomp != 4) return 2;
     static std::atomic<int> struct_size_shared{656};                       // libjpeg-turbo 2.x, v8 ABI, x86-64; corrected by the handshake
     int struct_size = struct_size_shared.load();
     // every buffer exists before the first libjpeg call: the geometry comes from the independent SOF parse above
     std::vector<unsigned char> store(4096 + 256), line((size_t)sw * scomp);
-    pix.resize((size_t)sw * shh * scomp);
+    const int ocomp = scomp == 1 ? 1 : 3;                                    // (four components come out as B G R, like OpenCV's)
+    pix.resize((size_t)sw * shh * ocomp);
     const int rc = jpeg_decode_raw(api, file.data(), file.size(), sw, shh, scomp, store.data(), store.size(), pix.data(), line.data(), &struct_size);
     struct_size_shared.store(struct_size);
-    if (rc == 0) { p.w = (int)sw; p.h = (int)shh; p.cn = scomp; p.depth = 8; p.data_ofs = 0; }
+    if (rc == 0) { p.w = (int)sw; p.h = (int)shh; p.cn = ocomp; p.depth = 8; p.data_ofs = 0; }
     return rc;
 }
 
@@ -654,7 +665,7 @@ stk_status load_image(stk_ctx* ctx, const char* path, std::vector<unsigned char>
         const int rc = jpeg_load(raw, p, file);
         if (rc == 0) { p.data_ofs = (size_t)-1; return STK_OK; }
         if (rc == 1) return fail(ctx, STK_BACKEND_ERROR, std::string("imread: cannot decode '") + path + "' (empty Mat -> cvtColor fails)");
-        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only grey / YCbCr JPEG through libjpeg-turbo's libjpeg.so.8 is decoded "
+        return fail(ctx, STK_NOT_IMPLEMENTED, std::string("imread: '") + path + "': only grey / YCbCr / CMYK JPEG through libjpeg-turbo's libjpeg.so.8 is decoded "
                                               "in this build (library " + (jpeg_api().ok ? "loaded" : "not found") + "); decode it on the caller's side");
     }
     if (has_ext(path, ".webp")) {

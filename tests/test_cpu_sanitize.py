@@ -58,6 +58,8 @@ def test_imread_under_asan_ubsan(tmp_path, write_png, write_tiff, write_tiff_til
             wl.WebPFree.argtypes = [C.c_void_p]; wl.WebPFree(out)
     except OSError:
         pass
+    from test_cpu_host import _cmyk_jpeg                   # a four-component JPEG (hand-made: Adobe CMYK, DC-only blocks)
+    (tmp_path / "cmyk.jpg").write_bytes(_cmyk_jpeg(rng.integers(0, 256, (2, 3, 4), dtype=np.uint8))); files.append(tmp_path / "cmyk.jpg")
     n_good = len(files)
     # truncations at every interesting place and byte-level garbage of each format
     for src in list(files):
