@@ -334,7 +334,9 @@ stk_status stk_warp_accumulate(stk_ctx* ctx, const stk_frames* frame /* n==1 */,
                                double alpha, int32_t accumulate, stk_image_f32* acc);
 
 /* scale_image (utils.rs:186-214) on an 8-bit grey image: aspect-preserving resize(INTER_AREA) so that the
- * smaller dimension becomes scale_down. out must hold new_w * new_h bytes (<= width * height). */
+ * SMALLER dimension becomes scale_down: new_w = (int)(w * f), new_h = (int)(h * f), f = scale_down / min(w, h). out must hold
+ * new_w * new_h bytes — more than width * height when scale_down exceeds the smaller dimension (the image is then enlarged,
+ * as the reference does for a landscape frame with height < scale_down < width: INTER_AREA's bilinear emulation). */
 stk_status stk_scale_image_grey(stk_ctx* ctx, const uint8_t* grey, int32_t width, int32_t height, int32_t location,
                                 float scale_down, uint8_t* out, int32_t* new_width, int32_t* new_height);
 /* The same on a 32FC1 grey (the grey of a float stack, e.g. float TIFF: ecc_match_scaling_down shrinks whatever depth cvtColor

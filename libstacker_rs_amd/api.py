@@ -583,7 +583,8 @@ class Stacker:
         f32 = np.asarray(grey).dtype == np.float32
         g = np.ascontiguousarray(grey, np.float32 if f32 else np.uint8)
         h, w = g.shape
-        out = np.empty(h * w, g.dtype)
+        f = float(np.float32(scale_down)) / min(w, h)              # utils.rs:191-199: the smaller dimension becomes scale_down
+        out = np.empty(max(h * w, (int(w * f) + 1) * (int(h * f) + 1)), g.dtype)
         nw, nh = C.c_int32(0), C.c_int32(0)
         fn = self._lib.stk_scale_image_grey_f32 if f32 else self._lib.stk_scale_image_grey
         self._check(fn(self._h, C.c_void_p(g.ctypes.data), w, h, HOST, float(scale_down), C.c_void_p(out.ctypes.data), C.byref(nw), C.byref(nh)))

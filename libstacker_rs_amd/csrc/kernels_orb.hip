@@ -193,10 +193,61 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const T* __restrict__ 
     store(sum);
 }
 
+// resize(INTER_AREA) when the image GROWS in a direction (scale_image makes the SMALLER dimension equal to scale_down, and the
+// reference only checks scale_down against the WIDTH — lib.rs:377, 876 — so a landscape stack with height < scale_down < width is
+// enlarged): "true area interpolation is only implemented for scale >= 1 in both directions; in other cases it is emulated using
+// some variant of bilinear interpolation" [OCV-RECALL: imgproc/src/resize.cpp, resize() with area_mode, resizeGeneric_,
+// HResizeLinear / VResizeLinear]: sx = floor(dx * scale), fx = (float)((dx + 1) - (sx + 1) * inv_scale), fx <= 0 ? 0 : fx - floor(fx)
+// (an integer enlargement replicates pixels); 8 bit: weights cvRound(w * 2048) as shorts, a row pass in int, then
+// ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2; f32: r = s0 * a0 + s1 * a1, d = r0 * b0 + r1 * b1. Columns whose
+// right-hand tap would leave the row (dx >= xmax) take the single pixel at full weight.
+__device__ __forceinline__ void area_up_coef(int d, int ssize, double scale, double inv_scale, int& s0, float& f, bool& single) {
+    int sx = (int)floor((double)d * scale);
+    float fx = (float)((double)(d + 1) - (double)(sx + 1) * inv_scale);
+    fx = fx <= 0.f ? 0.f : fx - floorf(fx);
+    single = sx + 1 >= ssize;
+    if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+    s0 = sx; f = fx;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_area_up_kernel(const T* __restrict__ src, int sw, int sh, T* __restrict__ dst, int dw, int dh,
+                                                             double scale_x, double scale_y, double inv_x, double inv_y) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int sx; float fx; bool single_x;
+    area_up_coef(x, sw, scale_x, inv_x, sx, fx, single_x);
+    // rows: yofs / beta are filled without the single-tap rule, the row pointers are merely clipped to the image
+    const int sy = (int)floor((double)y * scale_y);
+    float fy = (float)((double)(y + 1) - (double)(sy + 1) * inv_y);
+    fy = fy <= 0.f ? 0.f : fy - floorf(fy);
+    const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+    const T* r0 = src + (size_t)y0 * sw;
+    const T* r1 = src + (size_t)y1 * sw;
+    const int x1 = min(sx + 1, sw - 1);
+    if constexpr (sizeof(T) == 1) {
+        const int a0 = (int)(short)__builtin_rintf((1.f - fx) * 2048.f), a1 = (int)(short)__builtin_rintf(fx * 2048.f);
+        const int b0 = (int)(short)__builtin_rintf((1.f - fy) * 2048.f), b1 = (int)(short)__builtin_rintf(fy * 2048.f);
+        const int h0 = single_x ? (int)r0[sx] * 2048 : (int)r0[sx] * a0 + (int)r0[x1] * a1;
+        const int h1 = single_x ? (int)r1[sx] * 2048 : (int)r1[sx] * a0 + (int)r1[x1] * a1;
+        dst[(size_t)y * dw + x] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    } else {
+        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+        const float h0 = single_x ? r0[sx] * 1.f : r0[sx] * a0 + r0[x1] * a1;
+        const float h1 = single_x ? r1[sx] * 1.f : r1[sx] * a0 + r1[x1] * a1;
+        dst[(size_t)y * dw + x] = h0 * b0 + h1 * b1;
+    }
+}
+
 hipError_t launch_resize_area(const void* src, int depth, int sw, int sh, void* dst, int dw, int dh, hipStream_t s) {
     if (depth != 8 && depth != 32) return hipErrorInvalidValue;
     dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;
+    if (!(scale_x >= 1.0 && scale_y >= 1.0)) {
+        if (depth == 8) resize_area_up_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)src, sw, sh, (uint8_t*)dst, dw, dh, scale_x, scale_y, inv_x, inv_y);
+        else resize_area_up_kernel<float><<<grid, 256, 0, s>>>((const float*)src, sw, sh, (float*)dst, dw, dh, scale_x, scale_y, inv_x, inv_y);
+        return hipGetLastError();
+    }
     const int ix = (int)std::lrint(scale_x), iy = (int)std::lrint(scale_y);
     const bool fast = std::fabs(scale_x - ix) < 2.220446049250313e-16 && std::fabs(scale_y - iy) < 2.220446049250313e-16;
     if (depth == 8) resize_area_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)src, sw, sh, (uint8_t*)dst, dw, dh, scale_x, scale_y, fast ? ix : 0, fast ? iy : 0);

@@ -435,7 +435,7 @@ static stk_status scale_image_grey_impl(stk_ctx* ctx, const void* grey, int dept
     if (!grey || !out || width <= 0 || height <= 0 || !new_width || !new_height) return fail(ctx, STK_INVALID_PARAMS, "bad arguments");
     int nw, nh;
     if (!(scale_down > 0) || !scaled_size(width, height, scale_down, nw, nh))
-        return fail(ctx, STK_BACKEND_ERROR, "resize(INTER_AREA): scale_down must give a non-empty image no larger than the input");
+        return fail(ctx, STK_BACKEND_ERROR, "resize(INTER_AREA): scale_down must give a non-empty image");
     (void)hipSetDevice(ctx->device);
     KeypointWorkspace* ws = ctx->kp;
     const size_t el = (size_t)depth / 8, ib = (size_t)width * height * el, ob = (size_t)nw * nh * el;

@@ -49,7 +49,10 @@ hipError_t launch_resize_area(const void* src, int depth, int sw, int sh, void* 
 inline bool scaled_size(int w, int h, float scale_down, int& nw, int& nh) {
     const double sf = w < h ? (double)scale_down / (double)w : (double)scale_down / (double)h;
     nw = (int)((double)w * sf); nh = (int)((double)h * sf);
-    return nw > 0 && nh > 0 && nw <= w && nh <= h;
+    // (may EXCEED the input: the smaller dimension becomes scale_down, and the callers' only check is scale_down < WIDTH
+    // (lib.rs:377, 876) — a landscape frame with height < scale_down < width is enlarged, resize(INTER_AREA) then runs its
+    // bilinear emulation: resize_area_up_kernel)
+    return nw > 0 && nh > 0 && (int64_t)nw * nh < ((int64_t)1 << 31);
 }
 hipError_t launch_fast_level(const uint8_t* img, int w, int h, int thr, int edge, int keep, uint8_t* score,
                              OrbLevelState* st, OrbCandidate* cand, int cap, OrbSelected* sel, int sel_cap,

@@ -287,7 +287,7 @@ int area_tab(int ssize, int dsize, double scale, std::vector<DecimateAlpha>& tab
 }
 }  // namespace
 
-// resize(src, dsize, INTER_AREA) for a single-channel image, 8-bit or f32, shrinking in both directions [OCV-RECALL:
+// resize(src, dsize, INTER_AREA) for a single-channel image, 8-bit or f32 [OCV-RECALL:
 // imgproc/src/resize.cpp]. Integer ratios take resizeAreaFast_: the 2 x 2 case is ResizeAreaFastVec's (a + b + c + d + 2) >> 2
 // for 8 bit (half rounds up) and the vector form ((a + b) + (c + d)) * 0.25f for f32 (its scalar tail of w mod the vector
 // width adds ((a + b) + c) + d: a last-bit difference on a few right-hand columns, not reproduced); other integer ratios sum
@@ -301,9 +301,52 @@ template <> inline float area_store<float>(float v) { return v; }
 
 template <typename T>
 int resize_area_t(const T* src, int sw, int sh, T* dst, int dw, int dh) {
-    if (dw <= 0 || dh <= 0 || dw > sw || dh > sh) return 3;
+    if (dw <= 0 || dh <= 0) return 3;
     constexpr bool U8 = sizeof(T) == 1;
-    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;
+    if (!(scale_x >= 1.0 && scale_y >= 1.0)) {
+        // The image grows in a direction: "true area interpolation is only implemented for scale >= 1; in other cases it is
+        // emulated using some variant of bilinear interpolation" — resize() with area_mode, then resizeGeneric_ with
+        // HResizeLinear / VResizeLinear [OCV-RECALL]. Tables first, as OpenCV fills them.
+        std::vector<int> xofs(dw), yofs(dh);
+        std::vector<float> fxs(dw), fys(dh);
+        int xmax = dw;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = cv_floor(dx * scale_x);
+            float fx = (float)((dx + 1) - (sx + 1) * inv_x);
+            fx = fx <= 0 ? 0.f : fx - (float)cv_floor(fx);
+            if (sx + 1 >= sw) { xmax = std::min(xmax, dx); if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+            xofs[dx] = sx; fxs[dx] = fx;
+        }
+        for (int dy = 0; dy < dh; dy++) {
+            const int sy = cv_floor(dy * scale_y);
+            float fy = (float)((dy + 1) - (sy + 1) * inv_y);
+            fy = fy <= 0 ? 0.f : fy - (float)cv_floor(fy);
+            yofs[dy] = sy; fys[dy] = fy;
+        }
+        auto clip = [](int v, int n) { return v < 0 ? 0 : v >= n ? n - 1 : v; };
+        for (int dy = 0; dy < dh; dy++) {
+            const T* S0 = src + (size_t)clip(yofs[dy], sh) * sw;
+            const T* S1 = src + (size_t)clip(yofs[dy] + 1, sh) * sw;
+            for (int dx = 0; dx < dw; dx++) {
+                const int sx = xofs[dx], sx1 = std::min(sx + 1, sw - 1);
+                if (U8) {
+                    const int a0 = (short)cv_round((1.f - fxs[dx]) * 2048), a1 = (short)cv_round(fxs[dx] * 2048);
+                    const int b0 = (short)cv_round((1.f - fys[dy]) * 2048), b1 = (short)cv_round(fys[dy] * 2048);
+                    const int h0 = dx >= xmax ? (int)S0[sx] * 2048 : (int)S0[sx] * a0 + (int)S0[sx1] * a1;
+                    const int h1 = dx >= xmax ? (int)S1[sx] * 2048 : (int)S1[sx] * a0 + (int)S1[sx1] * a1;
+                    dst[(size_t)dy * dw + dx] = (T)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+                } else {
+                    const float a0 = 1.f - fxs[dx], a1 = fxs[dx], b0 = 1.f - fys[dy], b1 = fys[dy];
+                    const float h0 = dx >= xmax ? (float)S0[sx] * 1.f : (float)S0[sx] * a0 + (float)S0[sx1] * a1;
+                    const float h1 = dx >= xmax ? (float)S1[sx] * 1.f : (float)S1[sx] * a0 + (float)S1[sx1] * a1;
+                    dst[(size_t)dy * dw + dx] = (T)(h0 * b0 + h1 * b1);
+                }
+            }
+        }
+        return 0;
+    }
     const int isx = sat_int(scale_x), isy = sat_int(scale_y);
     if (std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON) {
         const float sc = 1.f / (isx * isy);

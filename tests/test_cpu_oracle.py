@@ -445,3 +445,24 @@ def test_resize_area_known_answers_and_f32():
     for dw, dh in ((16, 12), (21, 16), (50, 37)):
         a, b = oracle.resize_area_u8(u, dw, dh).astype(int), oracle.resize_area_f32(u.astype(np.float32), dw, dh)
         assert np.abs(a - b).max() <= 0.5 + 1e-4
+
+
+def test_resize_area_enlarging_is_the_bilinear_emulation():
+    """scale_image enlarges when scale_down exceeds the frame's smaller dimension (the reference only checks it against the WIDTH,
+    lib.rs:377, 876): resize(INTER_AREA) then runs "some variant of bilinear interpolation" [OCV-RECALL] — weights from
+    fx = (dx + 1) - (sx + 1) * inv_scale. Closed forms: an integer enlargement replicates pixels, 1.5 x alternates copies and
+    half-way blends (8 bit: rounded half up by the fixed-point column pass)."""
+    rng = np.random.default_rng(13)
+    u = rng.integers(0, 256, (6, 8), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_area_u8(u, 16, 12), np.repeat(np.repeat(u, 2, axis=0), 2, axis=1))
+    assert np.array_equal(oracle.resize_area_u8(u, 24, 18), np.repeat(np.repeat(u, 3, axis=0), 3, axis=1))
+    f = rng.random((6, 8), dtype=np.float32)
+    assert np.array_equal(oracle.resize_area_f32(f, 16, 12), np.repeat(np.repeat(f, 2, axis=0), 2, axis=1))
+    row = np.array([[10, 11, 20, 40]], np.uint8)
+    assert oracle.resize_area_u8(row, 6, 1).tolist() == [[10, 11, 11, 20, 30, 40]]      # S0, (S0 + S1) / 2 rounded up, S1, S2, (S2 + S3) / 2, S3
+    got = oracle.resize_area_f32(row.astype(np.float32), 6, 1)
+    assert got.tolist() == [[10.0, 10.5, 11.0, 20.0, 30.0, 40.0]]
+    # any enlargement: the weights of a pixel are an area-overlap split, so a constant image stays constant and the mean is kept
+    big = oracle.resize_area_f32(f, 13, 11)
+    assert abs(float(big.mean()) - float(f.mean())) < 0.02 and big.min() >= f.min() - 1e-6 and big.max() <= f.max() + 1e-6
+    assert (oracle.resize_area_u8(np.full((5, 7), 93, np.uint8), 12, 9) == 93).all()

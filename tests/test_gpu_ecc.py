@@ -300,6 +300,13 @@ def test_ecc_match_scaling_down_matches_oracle(stacker):
                                iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
     for i in (1, 2):                                             # full-size truth (homography run)
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 4.0 or motion != MotionType.Homography
+    # scale_down between the height and the width: the greys are ENLARGED (INTER_AREA's bilinear emulation), as in the reference
+    out, stats = stacker.ecc_match(list(frames), PARAMS, scale_down_width=540.0, return_stats=True)
+    ref, warps, iters = oracle.ecc_match(list(frames), scale_down_width=540.0)
+    for i in (1, 2):
+        assert synth.corner_error(stats[i]["warp"], warps[i], 640, 480) <= 0.1
+        assert stats[i]["iterations"] == int(iters[i])
+    assert_ecc_stack_close(out, ref, frames, warps, label="scale_down 540 on 640x480 (enlarging)", iters=[s["iterations"] for s in stats[1:]], iters_ref=iters[1:])
     from libstacker_rs_amd import InvalidParams
     with pytest.raises(InvalidParams):
         stacker.ecc_match(list(frames), PARAMS, scale_down_width=640.0)     # lib.rs:876

@@ -195,6 +195,12 @@ def test_scale_image_inter_area_bit_exact(stacker):
     assert (stacker.scale_image_grey(two, 8.0) == 1).all()
     quarter = np.zeros((32, 32), np.uint8); quarter[0::4, 0::4] = 8         # every 4 x 4 cell sums to 8: 0.5 -> 0
     assert (stacker.scale_image_grey(quarter, 8.0) == 0).all()
+    # scale_down above the smaller dimension ENLARGES (the reference checks it against the width only): INTER_AREA's bilinear emulation
+    for sd in (560.0, 600.5, 960.0):                          # 480 -> 560 (x 7/6), 600 (fractional), 960 (x 2: pixel replication)
+        nw, nh = oracle.scaled_size(640, 480, sd)
+        got = stacker.scale_image_grey(g, sd)
+        assert got.shape == (nh, nw) and nw > 640 and np.array_equal(got, oracle.resize_area_u8(g, nw, nh)), sd
+    assert np.array_equal(stacker.scale_image_grey(g, 960.0), np.repeat(np.repeat(g, 2, axis=0), 2, axis=1))
     # a 32FC1 grey (float stacks; round 4): the same tables without the rounding, bit for bit against the oracle
     f = rng.random((480, 640), dtype=np.float32) * 255
     for sd in (200.0, 240.0, 160.0, 333.0, 97.5):              # 240 -> 2 x 2 (vector form), 160 -> 3 x 3 (groups of four), others fractional
@@ -202,6 +208,27 @@ def test_scale_image_inter_area_bit_exact(stacker):
         got = stacker.scale_image_grey(f, sd)
         assert got.dtype == np.float32 and got.shape == (nh, nw)
         assert np.array_equal(got, oracle.resize_area_f32(f, nw, nh)), sd
+    for sd in (560.0, 600.5):
+        nw, nh = oracle.scaled_size(640, 480, sd)
+        assert np.array_equal(stacker.scale_image_grey(f, sd), oracle.resize_area_f32(f, nw, nh)), sd
+
+
+def test_keypoint_match_scale_down_between_height_and_width_enlarges_like_the_reference(stacker, kp_stack):
+    """lib.rs:377 rejects scale_down_width >= the frame's WIDTH only; scale_image (utils.rs:186-214) then makes the SMALLER dimension
+    equal to it — for landscape frames a value between height and width enlarges the greys ORB runs on (round 4; the engine
+    used to answer InvalidParams)."""
+    frames, G = kp_stack
+    h, w = frames[0].shape[:2]
+    assert h < w
+    sd = float(h) * 1.125
+    dropped, out, stats = stacker.keypoint_match(list(frames[:4]), PARAMS, scale_down_width=sd, return_stats=True)
+    d_o, ref, Hs, status = oracle.keypoint_match(list(frames[:4]), details=True, scale_down_width=sd)
+    assert dropped == d_o
+    for i in range(1, 4):
+        assert (stats[i]["status"] == 0) == (status[i] == 0)
+        if status[i] == 0:
+            assert np.allclose(stats[i]["warp"], Hs[i], rtol=H_RTOL, atol=1e-9)
+    assert_stack_close(out, ref)
 
 
 def test_keypoint_match_scale_down_matches_oracle(stacker, kp_stack):
