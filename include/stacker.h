@@ -229,12 +229,14 @@ stk_status stk_keypoint_match(stk_ctx* ctx, const stk_frames* frames,
  * the frame's own size, and warp_perspective's dsize is the FIRST frame's (lib.rs:166, 200-204, 290-299) — `out` has
  * geometry[0]'s size. geometry: n entries (frames->width / height / row_stride_bytes are ignored), or NULL = the stack of
  * one geometry `frames` describes; a stack whose entries are all equal takes the batched pipeline of stk_keypoint_match,
- * any other goes frame by frame through the same stages (same per-frame results). 8-bit BGR frames, no scale_down_width.
+ * any other goes frame by frame through the same stages (same per-frame results). 8-bit BGR(A) frames. scale_down_width > 0 is
+ * keypoint_match_scale_down (lib.rs:355-601) on such a stack: validated against the FIRST frame's width, every grey shrunk
+ * (or enlarged) by scale_image to ITS OWN smaller dimension = scale_down_width, the homography rescaled by that frame's own ratios.
  * (ecc_match has no such form: on frames of differing size the reference fails in cv::add, lib.rs:809 —
  * stk_ecc_match_files reports that as STK_BACKEND_ERROR.) */
 stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, const stk_frame_geometry* geometry,
-                                    const stk_keypoint_params* params, stk_image_f32* out, int32_t* dropped,
-                                    stk_frame_stats* stats_or_null);
+                                    const stk_keypoint_params* params, float scale_down_width, stk_image_f32* out,
+                                    int32_t* dropped, stk_frame_stats* stats_or_null);
 /* ecc_match(files, params, scale_down_width) -> Mat. */
 stk_status stk_ecc_match(stk_ctx* ctx, const stk_frames* frames,
                          const stk_ecc_params* params, float scale_down_width,

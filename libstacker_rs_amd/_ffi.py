@@ -73,7 +73,7 @@ SIGNATURES = {
     "stk_keypoint_match": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(KeypointParams), C.c_float,
                                       C.POINTER(ImageF32), C.POINTER(C.c_int32), C.POINTER(FrameStats)]),
     "stk_keypoint_match_mixed": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(FrameGeometry), C.POINTER(KeypointParams),
-                                            C.POINTER(ImageF32), C.POINTER(C.c_int32), C.POINTER(FrameStats)]),
+                                            C.c_float, C.POINTER(ImageF32), C.POINTER(C.c_int32), C.POINTER(FrameStats)]),
     "stk_ecc_match": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(EccParams), C.c_float,
                                  C.POINTER(ImageF32), C.POINTER(FrameStats)]),
     "stk_ecc_match_shard": (c_status, [C.c_void_p, C.POINTER(Frames), C.POINTER(EccParams), C.c_float, C.c_int32,

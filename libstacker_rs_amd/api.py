@@ -298,7 +298,7 @@ class Stacker:
         self._check(st)
         return (out, self._stats_list(stats, m.n)) if return_stats else out
 
-    def _keypoint_match_mixed(self, frames, params: KeyPointMatchParameters, return_stats: bool):
+    def _keypoint_match_mixed(self, frames, params: KeyPointMatchParameters, return_stats: bool, scale_down_width=None):
         """Frames of differing size (host arrays, HxWx3 u8): ORB at each frame's own size, every frame warped into the FIRST
         frame's size, as the reference does (lib.rs:166, 200-204, 290-299) — stk_keypoint_match_mixed."""
         arrs = [np.ascontiguousarray(f.cpu().numpy() if _is_torch(f) else f) for f in frames]
@@ -316,15 +316,13 @@ class Stacker:
         stats = (_ffi.FrameStats * n)()
         dropped = C.c_int32(0)
         p = params._c()
-        self._check(self._lib.stk_keypoint_match_mixed(self._h, C.byref(fr), geo, C.byref(p), C.byref(img), C.byref(dropped), stats))
+        self._check(self._lib.stk_keypoint_match_mixed(self._h, C.byref(fr), geo, C.byref(p), float(scale_down_width or 0.0), C.byref(img), C.byref(dropped), stats))
         return (dropped.value, out, self._stats_list(stats, n)) if return_stats else (dropped.value, out)
 
     def keypoint_match(self, files, params: KeyPointMatchParameters, scale_down_width: Optional[float] = None,
                        return_stats: bool = False):
         if isinstance(files, (list, tuple)) and len({tuple(f.shape) for f in files}) > 1:
-            if scale_down_width:
-                raise NotImplementedYet("scale_down_width on frames of differing size")
-            return self._keypoint_match_mixed(files, params, return_stats)
+            return self._keypoint_match_mixed(files, params, return_stats, scale_down_width)
         m = self._marshal(files)
         if m.n == 0:
             raise NotEnoughFiles("Not enough files")

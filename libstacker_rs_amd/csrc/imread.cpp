@@ -800,7 +800,6 @@ stk_status match_files(stk_ctx* ctx, const char* const* paths, int32_t n, Call c
 // host threads), then stk_keypoint_match_mixed on the host frames
 stk_status keypoint_files_mixed(stk_ctx* ctx, const char* const* paths, int32_t n, const stk_keypoint_params* params, float scale_down_width,
                                 stk_image_f32* out, int32_t* dropped, stk_frame_stats* stats) {
-    if (scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "scale_down_width on frames of differing size");
     std::vector<std::vector<unsigned char>> pix(n);
     std::vector<stk_frame_geometry> geo(n);
     std::vector<Pnm> heads(n);
@@ -836,7 +835,7 @@ stk_status keypoint_files_mixed(stk_ctx* ctx, const char* const* paths, int32_t 
     stk_frames fr{};
     fr.data = ptrs.data(); fr.n = n; fr.width = heads[0].w; fr.height = heads[0].h; fr.channels = heads[0].cn; fr.depth = heads[0].depth;
     fr.location = STK_HOST;
-    return stk_keypoint_match_mixed(ctx, &fr, geo.data(), params, out, dropped, stats);
+    return stk_keypoint_match_mixed(ctx, &fr, geo.data(), params, scale_down_width, out, dropped, stats);
 }
 
 }  // namespace

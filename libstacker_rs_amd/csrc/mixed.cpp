@@ -22,8 +22,8 @@ constexpr int MIXED_MAX_KP = 4096;      // rows of the stage-level ORB call (ORB
 extern "C" {
 
 stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, const stk_frame_geometry* geometry,
-                                    const stk_keypoint_params* params, stk_image_f32* out, int32_t* dropped_out,
-                                    stk_frame_stats* stats) {
+                                    const stk_keypoint_params* params, float scale_down_width, stk_image_f32* out,
+                                    int32_t* dropped_out, stk_frame_stats* stats) {
     if (!ctx) return STK_INVALID_PARAMS;
     if (!frames || !frames->data || frames->n < 0) return fail(ctx, STK_INVALID_PARAMS, "null frames");
     if (frames->n == 0) return fail(ctx, STK_NOT_ENOUGH_FILES, "Not enough files");
@@ -40,7 +40,7 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
     if (uniform) {
         stk_frames f = *frames;
         if (geometry) { f.width = geometry[0].width; f.height = geometry[0].height; f.row_stride_bytes = geometry[0].row_stride_bytes; }
-        return stk_keypoint_match(ctx, &f, params, 0.f, out, dropped_out, stats);
+        return stk_keypoint_match(ctx, &f, params, scale_down_width, out, dropped_out, stats);
     }
     if (ctx->multi) return fail(ctx, STK_NOT_IMPLEMENTED, "frames of differing size on a multi-device context");
     if (!params) return fail(ctx, STK_INVALID_PARAMS, "null params");
@@ -50,6 +50,10 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
     if (params->border_mode < 0 || params->border_mode > 4)
         return fail(ctx, params->border_mode == STK_BORDER_TRANSPARENT ? STK_NOT_IMPLEMENTED : STK_BACKEND_ERROR, "unsupported border mode");
     const int dw = geometry[0].width, dh = geometry[0].height;
+    const bool scaled = scale_down_width > 0;
+    if (scaled && scale_down_width >= (float)dw)        // lib.rs:377-382: against the first image only
+        return fail(ctx, STK_INVALID_PARAMS, "scale_down_to was larger (or equal) to the full image width: full_size:" +
+                                              std::to_string(dw) + ", scale_down_to:" + std::to_string(scale_down_width));
     stk_status st;
     if ((st = image_check(ctx, out, dw, dh, cn))) return st;
     if (out->row_stride_bytes) return fail(ctx, STK_INVALID_PARAMS, "output must be tightly packed");
@@ -73,8 +77,17 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
     }
     const bool host = frames->location == STK_HOST;
     if (host) HIP_TRY(ctx->frames.reserve(max_bytes));
-    HIP_TRY(ctx->blur_tmp.reserve(max_px));                        // the frame's grey image (u8)
+    size_t max_small = 0;
+    if (scaled)
+        for (int i = 0; i < n; i++) {
+            int ew, eh;
+            if (!stk::scaled_size(geometry[i].width, geometry[i].height, scale_down_width, ew, eh))
+                return fail(ctx, STK_INVALID_PARAMS, "frame " + std::to_string(i) + ": scale_down_width gives an empty image");
+            max_small = std::max(max_small, (size_t)ew * eh);
+        }
+    HIP_TRY(ctx->blur_tmp.reserve(max_px + 256 + max_small));      // the frame's grey image (u8), and behind it its scale_image
     uint8_t* grey = ctx->blur_tmp.as<uint8_t>();
+    uint8_t* small = grey + ((max_px + 255) & ~(size_t)255);
 
     std::vector<float> kp0((size_t)MIXED_MAX_KP * 7), kp((size_t)MIXED_MAX_KP * 7);
     std::vector<uint8_t> de0((size_t)MIXED_MAX_KP * 32), de((size_t)MIXED_MAX_KP * 32);
@@ -97,7 +110,13 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
         float* kps = i == 0 ? kp0.data() : kp.data();
         uint8_t* des = i == 0 ? de0.data() : de.data();
         int nk = 0;
-        if ((st = stk_orb_detect_and_compute(ctx, grey, w, h, STK_DEVICE, MIXED_MAX_KP, kps, des, &nk))) return st;   // lib.rs:161-175, 200-204
+        int ow = w, oh = h;                                  // the size ORB runs at
+        const uint8_t* orb_in = grey;
+        if (scaled) {                                        // utils::scale_image on this frame's grey (lib.rs:389, 429)
+            if ((st = stk_scale_image_grey(ctx, grey, w, h, STK_DEVICE, scale_down_width, small, &ow, &oh))) return st;
+            orb_in = small;
+        }
+        if ((st = stk_orb_detect_and_compute(ctx, orb_in, ow, oh, STK_DEVICE, MIXED_MAX_KP, kps, des, &nk))) return st;   // lib.rs:161-175, 200-204
         double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         bool ok = true;
         int n_matches = 0, n_inliers = 0;
@@ -131,7 +150,11 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
                                               H, mask.data(), &found))) return st;
                 if (found) {
                     const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
-                    ok = std::fabs(det) >= 1e-6;                                                                 // lib.rs:284
+                    ok = std::fabs(det) >= 1e-6;                                                                 // lib.rs:284 / 521 (on the small-image H)
+                    if (ok && scaled) {                      // adjust_homography_for_scale_f64(h_small, THIS frame's small grey, THIS frame): utils.rs:229-239
+                        const double sx = (double)w / (double)ow, sy = (double)h / (double)oh;
+                        H[2] *= sx; H[5] *= sy; H[6] /= sx; H[7] /= sy;
+                    }
                     for (uint8_t m : mask) n_inliers += m != 0;
                 }
             }

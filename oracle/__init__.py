@@ -220,7 +220,7 @@ def keypoint_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0
                    n_threads: int = 0, details: bool = False, scale_down_width=None):
     """keypoint_match_no_scale (lib.rs:146-353) with the documented drop semantics -> (dropped, image).
     Frames may differ in size: each is described at its own size (lib.rs:200-204) and warped into the first frame's
-    (lib.rs:290-299) — no scale_down_width then."""
+    (lib.rs:290-299); with scale_down_width every grey is scaled to ITS OWN smaller dimension = scale_down_width (lib.rs:429)."""
     frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
     n = len(frames)
     h, w, _ = frames[0].shape
@@ -231,12 +231,11 @@ def keypoint_match(frames, method: int = 8, ransac_reproj_threshold: float = 5.0
     status = np.zeros(n, np.int32)
     dropped = C.c_int(0)
     if len({f.shape for f in frames}) > 1:
-        assert not scale_down_width
         ws = np.array([f.shape[1] for f in frames], np.int32)
         hs = np.array([f.shape[0] for f in frames], np.int32)
         rc = lib().orc_keypoint_match_sized(ptrs, n, _p(ws), _p(hs), int(method), C.c_double(ransac_reproj_threshold),
                                             C.c_float(match_keep_ratio), C.c_float(match_ratio), int(border_mode), _p(bv),
-                                            _p(out), C.byref(dropped), _p(Hs), _p(status), int(n_threads))
+                                            C.c_float(scale_down_width or 0.0), _p(out), C.byref(dropped), _p(Hs), _p(status), int(n_threads))
         if rc:
             raise RuntimeError("orc_keypoint_match_sized rc=%d" % rc)
         return (dropped.value, out, Hs, status) if details else (dropped.value, out)

@@ -437,18 +437,17 @@ int orc_keypoint_match(const void* const* frames, int n, int w, int h, int metho
 }
 
 int orc_keypoint_match_sized(const void* const* frames, int n, const int* ws, const int* hs, int method, double thr, float keep_ratio,
-                             float match_ratio, int border_mode, const double* border_value, float* out,
+                             float match_ratio, int border_mode, const double* border_value, float scale_down, float* out,
                              int* dropped_out, double* H_out, int* status_out, int n_threads) {
     if (n <= 0) return 1;
     return keypoint_match_impl(frames, n, ws[0], hs[0], ws, hs, method, thr, keep_ratio, match_ratio, border_mode, border_value,
-                               0.f, out, dropped_out, H_out, status_out, n_threads);
+                               scale_down, out, dropped_out, H_out, status_out, n_threads);
 }
 
 static int keypoint_match_impl(const void* const* frames, int n, int w, int h, const int* ws, const int* hs, int method, double thr,
                                float keep_ratio, float match_ratio, int border_mode, const double* border_value, float scale_down,
                                float* out, int* dropped_out, double* H_out, int* status_out, int n_threads) {
     if (n <= 0) return 1;
-    if (ws && scale_down > 0) return 3;
     const size_t npx = (size_t)w * h, nel = npx * 3;
     int ew = w, eh = h;
     if (scale_down > 0) {
@@ -484,11 +483,16 @@ static int keypoint_match_impl(const void* const* frames, int n, int w, int h, c
         if (i > 0) {
             std::vector<uint8_t> g((size_t)wi * hi);
             orc_grey(frames[i], 8, wi, hi, 0, g.data());
-            if (scale_down > 0) { std::vector<uint8_t> sm((size_t)ew * eh); orc_resize_area_u8(g.data(), w, h, sm.data(), ew, eh); g.swap(sm); }
+            // scale_image on THIS frame's grey: its own smaller dimension becomes scale_down (lib.rs:429, utils.rs:186-214)
+            int ewi = wi, ehi = hi;
+            if (scale_down > 0) {
+                if (orc_scaled_size(wi, hi, scale_down, &ewi, &ehi)) { err = 3; continue; }
+                std::vector<uint8_t> sm((size_t)ewi * ehi); orc_resize_area_u8(g.data(), wi, hi, sm.data(), ewi, ehi); g.swap(sm);
+            }
             std::vector<float> kp((size_t)MAXKP * 7);
             std::vector<uint8_t> de((size_t)MAXKP * 32);
             int nk = 0;
-            orc_orb_detect_and_compute(g.data(), ws ? wi : ew, hs ? hi : eh, MAXKP, kp.data(), de.data(), &nk);
+            orc_orb_detect_and_compute(g.data(), ewi, ehi, MAXKP, kp.data(), de.data(), &nk);
             // query = frame-0 descriptors, train = frame-i descriptors (lib.rs:208-219)
             std::vector<int> knn((size_t)std::max(n0, 1) * 4);
             orc_bf_knn2_hamming(de0.data(), n0, de.data(), nk, knn.data());
@@ -517,8 +521,8 @@ static int keypoint_match_impl(const void* const* frames, int n, int w, int h, c
                 else {
                     const double det = Hm[0] * (Hm[4] * Hm[8] - Hm[5] * Hm[7]) - Hm[1] * (Hm[3] * Hm[8] - Hm[5] * Hm[6]) + Hm[2] * (Hm[3] * Hm[7] - Hm[4] * Hm[6]);
                     if (std::fabs(det) < 1e-6) status = 1;
-                    else if (scale_down > 0) {              // adjust_homography_for_scale_f64, utils.rs:229-239
-                        const double sx = (double)w / (double)ew, sy = (double)h / (double)eh;
+                    else if (scale_down > 0) {              // adjust_homography_for_scale_f64(h_small, this frame's small grey, this frame), utils.rs:229-239
+                        const double sx = (double)wi / (double)ewi, sy = (double)hi / (double)ehi;
                         Hm[2] *= sx; Hm[5] *= sy; Hm[6] /= sx; Hm[7] /= sy;
                     }
                 }

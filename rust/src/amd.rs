@@ -270,11 +270,10 @@ pub(crate) fn keypoint_match(
     let (out, mut img) = new_output(frames.width, frames.height, frames.channels)?;
     let st = if stack.uniform {
         unsafe { stk_keypoint_match(ctx, &frames, &p, sdw, &mut img, &mut dropped, std::ptr::null_mut()) }
-    } else if scale_down_width.is_some() {
-        return Err(StackerError::NotImplemented); // keypoint_match_scale_down on frames of differing size
     } else {
+        // frames of differing size, with or without scale_down_width (lib.rs:355-601 scales every grey by ITS OWN factor)
         unsafe {
-            stk_keypoint_match_mixed(ctx, &frames, stack.geometry.as_ptr(), &p, &mut img, &mut dropped, std::ptr::null_mut())
+            stk_keypoint_match_mixed(ctx, &frames, stack.geometry.as_ptr(), &p, sdw, &mut img, &mut dropped, std::ptr::null_mut())
         }
     };
     if st == STK_OK { Ok((dropped, out)) } else { Err(to_err(ctx, st)) }

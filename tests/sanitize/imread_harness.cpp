@@ -8,7 +8,7 @@ extern "C" {
 stk_status stk_keypoint_match(stk_ctx*, const stk_frames*, const stk_keypoint_params*, float, stk_image_f32*, int32_t*, stk_frame_stats*) { return STK_HIP_ERROR; }
 stk_status stk_ecc_match(stk_ctx*, const stk_frames*, const stk_ecc_params*, float, stk_image_f32*, stk_frame_stats*) { return STK_HIP_ERROR; }
 stk_status stk_hybrid_match(stk_ctx*, const stk_frames*, const stk_keypoint_params*, const stk_ecc_params*, stk_image_f32*, stk_frame_stats*) { return STK_HIP_ERROR; }
-stk_status stk_keypoint_match_mixed(stk_ctx*, const stk_frames*, const stk_frame_geometry*, const stk_keypoint_params*, stk_image_f32*, int32_t*, stk_frame_stats*) { return STK_HIP_ERROR; }
+stk_status stk_keypoint_match_mixed(stk_ctx*, const stk_frames*, const stk_frame_geometry*, const stk_keypoint_params*, float, stk_image_f32*, int32_t*, stk_frame_stats*) { return STK_HIP_ERROR; }
 }
 
 int main(int argc, char** argv) {

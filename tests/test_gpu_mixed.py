@@ -33,8 +33,30 @@ def test_mixed_sizes_match_the_oracle(stacker):
         assert np.allclose(stats[i]["warp"], Hs[i], rtol=2e-7, atol=1e-9)          # the LM floor, test_gpu_homography.py
         assert synth.corner_error(stats[i]["warp"], G[i], 640, 480) <= 1.0          # generator ground truth
     assert_stack_close(out, ref)
-    with pytest.raises(NotImplementedYet):
-        stacker.keypoint_match(fr, KP, scale_down_width=200.0)
+
+
+def test_mixed_sizes_with_scale_down_match_the_oracle(stacker):
+    """keypoint_match_scale_down on such a stack (lib.rs:355-601): the width check is against the FIRST frame only, every grey is
+    scaled so that ITS OWN smaller dimension equals scale_down_width (frames of differing size get differing factors) and the
+    small-image homography is rescaled by that frame's own ratios (utils.rs:229-239) — reproduced as written, whatever it means
+    geometrically for frames whose factors differ."""
+    fr, G = _mixed_stack()
+    from libstacker_rs_amd import InvalidParams
+    for sd in (300.0, 420.0):                              # 420 > frame 3's height 333: that grey is ENLARGED
+        d_ref, ref, Hs, status = oracle.keypoint_match(fr, details=True, scale_down_width=sd)
+        dropped, out, stats = stacker.keypoint_match(fr, KP, scale_down_width=sd, return_stats=True)
+        assert out.shape == fr[0].shape and dropped == d_ref
+        for i in range(1, len(fr)):
+            assert (stats[i]["status"] == 0) == (int(status[i]) == 0)
+            if int(status[i]) == 0:
+                # (frames scaled by differing factors: a 0.69 x similarity on few hundred matches — the LM floor in the two small
+                # perspective entries is a few 1e-6 relative, cf. test_cpu_oracle.py::test_homography_lm_floor; what counts is
+                # where the corners land)
+                assert np.allclose(stats[i]["warp"], Hs[i], rtol=5e-6, atol=1e-9)
+                assert synth.corner_error(stats[i]["warp"], Hs[i], fr[i].shape[1], fr[i].shape[0]) <= 1e-3
+        assert_stack_close(out, ref)
+    with pytest.raises(InvalidParams):
+        stacker.keypoint_match(fr, KP, scale_down_width=640.0)         # lib.rs:377: >= the first frame's width
 
 
 def test_frame_by_frame_route_equals_the_batched_pipeline(stacker):
@@ -58,7 +80,7 @@ def test_frame_by_frame_route_equals_the_batched_pipeline(stacker):
     stats = (_ffi.FrameStats * n)()
     dropped = C.c_int32(-1)
     p = KP._c()
-    stacker._check(stacker._lib.stk_keypoint_match_mixed(stacker._h, C.byref(frs), geo, C.byref(p), C.byref(img), C.byref(dropped), stats))
+    stacker._check(stacker._lib.stk_keypoint_match_mixed(stacker._h, C.byref(frs), geo, C.byref(p), 0.0, C.byref(img), C.byref(dropped), stats))
     assert dropped.value == d0
     for i in range(1, n):
         assert np.array_equal(np.array(list(stats[i].warp)).reshape(3, 3), s0[i]["warp"])
@@ -68,7 +90,7 @@ def test_frame_by_frame_route_equals_the_batched_pipeline(stacker):
     dropped.value = -1
     tight = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
     frs2 = _ffi.Frames(C.cast(tight, C.POINTER(C.c_void_p)), n, 320, 240, 3, 8, 0, 0)
-    stacker._check(stacker._lib.stk_keypoint_match_mixed(stacker._h, C.byref(frs2), None, C.byref(p), C.byref(img), C.byref(dropped), None))
+    stacker._check(stacker._lib.stk_keypoint_match_mixed(stacker._h, C.byref(frs2), None, C.byref(p), 0.0, C.byref(img), C.byref(dropped), None))
     assert dropped.value == d0 and np.array_equal(out, base)
 
 
