@@ -42,7 +42,7 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
         if (geometry) { f.width = geometry[0].width; f.height = geometry[0].height; f.row_stride_bytes = geometry[0].row_stride_bytes; }
         return stk_keypoint_match(ctx, &f, params, scale_down_width, out, dropped_out, stats);
     }
-    if (ctx->multi) return fail(ctx, STK_NOT_IMPLEMENTED, "frames of differing size on a multi-device context");
+    // (a multi-device context takes such a stack on its own device alone, frame by frame: the owning context is member 0)
     if (!params) return fail(ctx, STK_INVALID_PARAMS, "null params");
     if (frames->channels != 3 && frames->channels != 4) return fail(ctx, STK_BACKEND_ERROR, "cvtColor(BGR2GRAY): frames must have 3 or 4 channels (utils.rs:136)");
     const int cn = frames->channels;

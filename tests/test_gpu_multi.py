@@ -55,6 +55,16 @@ def test_multi_keypoint_and_hybrid_equal_single(stacker, multi):
     assert np.max(np.abs(h1 - h2)) <= 1e-6               # per-frame results identical; the order of the f32 adds differs
 
 
+def test_multi_context_takes_frames_of_differing_size_on_its_first_device(stacker, multi):
+    # what the Rust shim's one shared context (rust/src/amd.rs) does with a stack of mixed sizes: the frame-by-frame route on member 0
+    frames, _ = synth.make_stack(4, 640, 480)
+    fr = frames.numpy()
+    mixed = [fr[0], np.ascontiguousarray(fr[1][:400, :600]), np.ascontiguousarray(fr[2][:470, :520]), np.ascontiguousarray(fr[3][:333, :639])]
+    d1, one = stacker.keypoint_match(mixed, KP)
+    d2, two = multi.keypoint_match(mixed, KP)
+    assert d1 == d2 and np.array_equal(one, two)
+
+
 def test_multi_more_devices_than_frames_and_errors(stacker, multi):
     frames, _ = synth.make_stack(2, 320, 240)
     fr = list(frames.numpy())
