@@ -140,7 +140,11 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
     if (frame < 0) return;
     SlotConst c;
     load_slot_const(sl, a, c);
+#ifdef STK_COL_PROBE_T0                                              // (timing probe: every slot reads template 0 — the template stream then comes out of the L2)
+    const float* __restrict__ T = a.templates;
+#else
     const float* __restrict__ T = a.templates + (size_t)frame * a.templ_plane_stride;
+#endif
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     __shared__ __attribute__((aligned(16))) char ring_all[4 * LWAVE];
     char* const ring = ring_all + wave * LWAVE;          // this wave's ring; nothing in it is shared between waves
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
             int issued = 0;                                      // transfers issued in the current step
             int loaded = 0;                                      // last frame-0 row in the ring (or on its way)
             auto dma_row = [&]() {                               // the next frame-0 row, LROW bytes from column xb on, into its slot
+#ifndef STK_COL_PROBE_NO_R                                        // (timing probe: no frame-0 transfers at all — results are garbage)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                              : : "s"(dst), "v"(l16), "s"(pR), "r"(ring) : "memory", "m0");
                 issued += 1;
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                                  : : "s"(dst), "v"(l16), "s"(pR), "n"(LK * LROW), "r"(ring) : "memory", "m0", "scc");
                     issued += 1;
                 }
+#endif
                 pR += row_bytes;
                 dst = dst + LROW == ring_lds + LK * LROW ? ring_lds : dst + LROW;
                 loaded++;
@@ -411,9 +417,16 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
             const char* pT = nullptr;                            // template row of the next dma_templ: pixel (this strip's column 0) minus (tr - 4 lane)
             auto dma_templ = [&](auto slot_tag) {                // the next template row, this lane's pixel, into ring slot SLOT
                 constexpr int SLOT = decltype(slot_tag)::value;
+#ifndef STK_COL_PROBE_NO_T                                        // (timing probe: no template transfers — results are garbage)
+#ifdef STK_COL_PROBE_T14                                          // (timing probe: three template rows of four come from template 0, i.e. out of the L2)
+                const char* const src = SLOT == 0 ? pT : pT - (size_t)frame * a.templ_plane_stride * 4;
+#else
+                const char* const src = pT;
+#endif
                 asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                             : : "s"(ring_lds), "v"(tr), "s"(pT), "n"(LTOFF + SLOT * 256), "r"(ring) : "memory", "m0", "scc");
+                             : : "s"(ring_lds), "v"(tr), "s"(src), "n"(LTOFF + SLOT * 256), "r"(ring) : "memory", "m0", "scc");
                 issued += 1;
+#endif
                 pT += (size_t)a.templ_row_stride * 4;            // (rows past the strip's end are fetched and never read: the buffer has the room)
             };
             typedef __attribute__((address_space(3))) const float lds_f;
