@@ -427,7 +427,11 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                              : : "s"(ring_lds), "v"(tr), "s"(src), "n"(LTOFF + SLOT * 256), "r"(ring) : "memory", "m0", "scc");
                 issued += 1;
 #endif
+#ifdef STK_COL_PROBE_TSEQ                                         // (timing probe: strip-major template addresses — a wave's rows are consecutive 256-byte pieces)
+                pT += 256;
+#else
                 pT += (size_t)a.templ_row_stride * 4;            // (rows past the strip's end are fetched and never read: the buffer has the room)
+#endif
             };
             typedef __attribute__((address_space(3))) const float lds_f;
             auto templ_sample = [&](auto slot_tag) {             // this lane's sample of the template row in ring slot SLOT
@@ -501,7 +505,11 @@ __global__ __launch_bounds__(256, STK_COL_WG) void ecc_iter_col_kernel(EccIterAr
                 dst = ring_lds + (unsigned)((loaded + 1) & (LK - 1)) * LROW;
                 const int want = max(i0, i1) + la;
                 while (loaded < want) dma_row();
+#ifdef STK_COL_PROBE_TSEQ
+                pT = (const char*)(T + ((size_t)col * a.th + y0) * 64) - (ring_lds + LTOFF);
+#else
                 pT = (const char*)(T + (size_t)y0 * a.templ_row_stride + col * 64) - (ring_lds + LTOFF);
+#endif
                 dma_templ(std::integral_constant<int, 0>{}); dma_templ(std::integral_constant<int, 1>{}); dma_templ(std::integral_constant<int, 2>{});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 read_taps(locate((float)y0, ca, ilo, ihi), top, bot);
