@@ -92,6 +92,49 @@ def test_png_paths_equal_frame_based(stacker, tmp_path, write_png):
     assert np.array_equal(stacker.ecc_match_files(paths, ecc), stacker.ecc_match(list(fr), ecc))
 
 
+def test_webp_paths_equal_frame_based(stacker, tmp_path):
+    # lossless WebP through the run-time libwebp (round 4): the decoded frames are the encoded ones, so the path-based call equals
+    # the frame-based one; a stack with alpha gives a four-channel result
+    import ctypes as C
+    try:
+        wl = C.CDLL("libwebp.so.7")
+    except OSError:
+        pytest.skip("libwebp.so.7 is not installed here")
+    wl.WebPFree.argtypes = [C.c_void_p]
+
+    def write_webp(path, img):
+        fn = wl.WebPEncodeLosslessBGRA if img.shape[2] == 4 else wl.WebPEncodeLosslessBGR
+        fn.restype = C.c_size_t
+        img = np.ascontiguousarray(img)
+        out = C.c_void_p()
+        n = fn(C.c_void_p(img.ctypes.data), C.c_int(img.shape[1]), C.c_int(img.shape[0]), C.c_int(img.strides[0]), C.byref(out))
+        assert n > 0
+        path.write_bytes(C.string_at(out, n))
+        wl.WebPFree(out)
+
+    frames, _ = synth.make_stack(3, 320, 240)
+    fr = frames.numpy()
+    paths = []
+    for i, f in enumerate(fr):
+        paths.append(tmp_path / f"frame_{i}.webp")
+        write_webp(paths[-1], f)
+    assert np.array_equal(stacker.imread(paths[1]), fr[1])
+    ecc = EccMatchParameters(MotionType.Homography, 5000, 1e-5, 5)
+    kp = KeyPointMatchParameters(RANSAC, 5.0, 0.80, 0.9)
+    assert np.array_equal(stacker.ecc_match_files(paths, ecc), stacker.ecc_match(list(fr), ecc))
+    d_f, out_f = stacker.keypoint_match_files(paths, kp)
+    d_a, out_a = stacker.keypoint_match(list(fr), kp)
+    assert d_f == d_a and np.array_equal(out_f, out_a)
+    alpha = np.full(fr.shape[:3] + (1,), 200, np.uint8)
+    fa = np.concatenate([fr, alpha], axis=3)
+    pa = []
+    for i, f in enumerate(fa):
+        pa.append(tmp_path / f"alpha_{i}.webp")
+        write_webp(pa[-1], f)
+    out4 = stacker.ecc_match_files(pa, ecc)
+    assert out4.shape == (240, 320, 4) and np.array_equal(out4, stacker.ecc_match(list(fa), ecc))
+
+
 def test_16bit_tiff_stack_through_hybrid_match_files(stacker, tmp_path, write_tiff):
     # BASELINE configs[4] end to end: a 16-bit TIFF stack on disk -> ORB-seeded ECC -> f32 image
     import ctypes
