@@ -47,6 +47,8 @@ enum { STK_MOTION_TRANSLATION = 0, STK_MOTION_EUCLIDEAN = 1, /* MotionType lib.r
        STK_MOTION_AFFINE = 2, STK_MOTION_HOMOGRAPHY = 3 };
 enum { STK_METHOD_LEAST_SQUARES = 0, STK_METHOD_LMEDS = 4, /* KeyPointMatchParameters::method lib.rs:51 */
        STK_METHOD_RANSAC = 8, STK_METHOD_RHO = 16 };
+/* (RHO and OpenCV's USAC numbers 32 .. 38: STK_NOT_IMPLEMENTED. Any other value: findHomography throws, stk_find_homography
+ * reports STK_BACKEND_ERROR, and the whole-stack calls skip every moving frame as lib.rs:275 does.) */
 enum { STK_BORDER_CONSTANT = 0, STK_BORDER_REPLICATE = 1, STK_BORDER_REFLECT = 2,
        STK_BORDER_WRAP = 3, STK_BORDER_REFLECT_101 = 4, STK_BORDER_TRANSPARENT = 5 };
 enum { STK_HOST = 0, STK_DEVICE = 1 };

@@ -491,6 +491,7 @@ stk_status stk_find_homography(stk_ctx* ctx, const float* src_pts, const float* 
     const int st = geom::find_homography_batch(ctx, ctx->stream, ctx->hg, &pr, 1, method, thr, &o);
     if (st) return (stk_status)st;
     if (o.rc == 7) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: RHO is not implemented");
+    if (method >= 32 && method <= 38) return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: the USAC methods are not implemented");
     if (o.rc != 0) return fail(ctx, STK_BACKEND_ERROR, "findHomography: needs at least 4 point pairs and a known method");
     *found = o.found;
     for (int k = 0; k < 9; k++) H[k] = o.H[k];
@@ -509,10 +510,16 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
     if (frames->depth != 8 && !(reduce16 && frames->depth == 16))   // ORB::detectAndCompute asserts an 8-bit image
         return fail(ctx, STK_BACKEND_ERROR, "ORB: only 8-bit images are supported");
     if (reduce16 && frames->depth == 16 && scale_down_width > 0) return fail(ctx, STK_NOT_IMPLEMENTED, "scale_down_width with 16-bit frames");
+    // findHomography's methods: 0 / LMEDS / RANSAC here; RHO and OpenCV >= 4.5's USAC family (32 .. 38) exist in the reference's
+    // OpenCV and are not restated -> STK_NOT_IMPLEMENTED. Any other value makes findHomography throw ("Unknown estimation method"),
+    // which keypoint_match turns into a SKIPPED frame (lib.rs:275: Err(_) => return Ok(None)): every moving frame is dropped then.
+    bool drop_all_moving = false;
     if (params->method != STK_METHOD_RANSAC && params->method != STK_METHOD_LEAST_SQUARES && params->method != STK_METHOD_LMEDS) {
         if (params->method == STK_METHOD_RHO)
             return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: RHO is not implemented");
-        return fail(ctx, STK_BACKEND_ERROR, "findHomography: unknown estimation method");
+        if (params->method >= 32 && params->method <= 38)
+            return fail(ctx, STK_NOT_IMPLEMENTED, "findHomography: the USAC methods are not implemented");
+        drop_all_moving = true;
     }
     if (params->border_mode < 0 || params->border_mode > 4)
         return fail(ctx, params->border_mode == STK_BORDER_TRANSPARENT ? STK_NOT_IMPLEMENTED : STK_BACKEND_ERROR, "unsupported border mode");
@@ -709,7 +716,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
             for (int m = 0; m < n_mov; m++)
                 if (!from_pts[m].empty()) { probs.push_back({from_pts[m].data(), to_pts[m].data(), (int)from_pts[m].size() / 2, nullptr}); owner.push_back(m); }
             std::vector<geom::HgOutcome> outc(probs.size());
-            if (!probs.empty()) {
+            if (!probs.empty() && !drop_all_moving) {           // (an unknown method: findHomography throws, the frame is skipped — `found` stays 0)
                 const int hst = geom::find_homography_batch(c, ts, c->hg, probs.data(), (int)probs.size(), params->method,
                                                             params->ransac_reproj_threshold, outc.data());
                 if (hst) return (stk_status)hst;
@@ -727,7 +734,7 @@ stk_status keypoint_align_impl(stk_ctx* ctx, const stk_frames* frames, const stk
                 R.n_inliers = o.n_inliers;
                 R.ok = true;
             }
-            if (ts != s && probs.empty()) HIP_TRY_C(c, hipStreamSynchronize(ts));         // (no homography call ended the batch on ts)
+            if (ts != s && (probs.empty() || drop_all_moving)) HIP_TRY_C(c, hipStreamSynchronize(ts));   // (no homography call ended the batch on ts)
         }
         HIP_TRY_C(c, hipStreamSynchronize(s));
         return STK_OK;

@@ -146,8 +146,11 @@ stk_status stk_keypoint_match_mixed(stk_ctx* ctx, const stk_frames* frames, cons
                 int found = 0;
                 std::vector<uint8_t> mask(ms.size());
                 // find_homography(dst_pts, src_pts): frame i -> frame 0 (lib.rs:267-276)
-                if ((st = stk_find_homography(ctx, dp.data(), sp.data(), (int)ms.size(), params->method, params->ransac_reproj_threshold,
-                                              H, mask.data(), &found))) return st;
+                const int mth = params->method;
+                const bool known = mth == STK_METHOD_LEAST_SQUARES || mth == STK_METHOD_LMEDS || mth == STK_METHOD_RANSAC || mth == STK_METHOD_RHO || (mth >= 32 && mth <= 38);
+                // (an unknown method: findHomography throws and the frame is skipped, lib.rs:275; RHO / USAC: STK_NOT_IMPLEMENTED from the stage)
+                if (known && (st = stk_find_homography(ctx, dp.data(), sp.data(), (int)ms.size(), mth, params->ransac_reproj_threshold,
+                                                       H, mask.data(), &found))) return st;
                 if (found) {
                     const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
                     ok = std::fabs(det) >= 1e-6;                                                                 // lib.rs:284 / 521 (on the small-image H)

@@ -165,6 +165,17 @@ def test_keypoint_match_errors(stacker, kp_stack):
     assert out.shape == frames[0].shape
     with pytest.raises(OpenCvError):
         stacker.keypoint_match([frames[0], np.ascontiguousarray(np.concatenate([frames[1][:400], frames[1][:400, :, :1]], -1))], PARAMS)
+    # a method findHomography does not know makes it throw, and keypoint_match turns the error into a skipped frame
+    # (lib.rs:275: Err(_) => return Ok(None)): every moving frame is dropped and the result is frame 0 alone (round 4; the
+    # engine used to fail the call). USAC's numbers (32 .. 38, OpenCV >= 4.5) and RHO are real methods: NotImplemented.
+    from libstacker_rs_amd import NotImplementedYet
+    d, out = stacker.keypoint_match(list(frames[:3]), KeyPointMatchParameters(7, 5.0, 0.80, 0.9))
+    d_o, ref = oracle.keypoint_match(list(frames[:3]), method=7)
+    assert d == d_o == 2 and np.array_equal(out, ref)
+    assert np.array_equal(out, frames[0].astype(np.float32) * np.float32(1.0 / 255.0))
+    for m in (16, 32, 38):
+        with pytest.raises(NotImplementedYet):
+            stacker.keypoint_match(list(frames[:2]), KeyPointMatchParameters(m, 5.0, 0.80, 0.9))
 
 
 def test_keypoint_match_border_mode_and_value(stacker, kp_stack):
